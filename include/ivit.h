@@ -1,0 +1,118 @@
+/*
+ * ivit.h - C ABI of the MI355X-native ViT forward engine (libivit.so, gfx950).
+ *
+ * This is the drop-in boundary under the reference's Python operator API.  The reference
+ * (0Marble/interactive-vit) has no native code: every node's arithmetic is the call
+ * `sub(x)` into torch's CPU kernels at main/context.py:79-88 (Model.compute), reached from
+ * Context.compute (main/context.py:143-147) <- views.compute (main/views.py:30-42).  The ViT model
+ * plugin (interactive_vit_amd/models/vit.py, modelled on static/models/vgg16.py:10-62) replaces that
+ * one call with the entry points below; SURVEY.md 8(b) lists what a C-ABI replacement must export.
+ *
+ * Conventions
+ *   - plain C types only; no Python or torch objects cross this boundary;
+ *   - every function returns 0 on success, non-zero on failure; the message of the last failure
+ *     on the calling thread is ivit_last_error().  The Python shim raises Exception(message), which
+ *     views.compute maps to HTTP 400 (main/views.py:40-42) - the reference's error convention;
+ *   - the caller owns in/out buffers and keeps them alive for the call; the engine owns its device
+ *     memory (bf16 weights, activation workspaces);
+ *   - an engine may be used from several host threads: calls on one handle are serialised inside;
+ *   - tensors are row-major, float32 at the boundary (the wire format is f32: main/message.py:41-59).
+ *
+ * Stages (the nodes of the plugin, SURVEY.md 8(a2')); L = config.layers:
+ *     0            transform      [B,3,S,S]  -> [B,3,S,S]   (x-mean)/std per channel
+ *     1            conv_proj      [B,3,S,S]  -> [B,Np,D]    unfold + GEMM + bias
+ *     2            tokens         [B,Np,D]   -> [B,N,D]     class token, + position embedding
+ *     3 .. 3+L-1   encoder.layers.i  [B,N,D] -> [B,N,D]     residual-inclusive transformer block
+ *     3+L          encoder.ln     [B,N,D]    -> [B,N,D]
+ *     4+L          cls            [B,N,D]    -> [B,D]
+ *     5+L          heads          [B,D]      -> [B,classes]
+ * A range [begin,end) of consecutive stages runs fused: intermediate activations stay on the device
+ * in the engine's internal layout (fp32 residual stream, bf16 GEMM operands).
+ */
+#ifndef IVIT_H
+#define IVIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVIT_ABI_VERSION 1
+
+typedef struct ivit_engine ivit_engine;
+
+typedef struct ivit_config {
+    int32_t image;      /* S */
+    int32_t patch;      /* p */
+    int32_t dim;        /* D */
+    int32_t heads;      /* H, D % H == 0, head dim in {64, 80, 128} or any multiple of 16 <= 128 */
+    int32_t layers;     /* L */
+    int32_t mlp;        /* hidden width of the MLP */
+    int32_t classes;
+    float   ln_eps;
+    int32_t device;     /* HIP device ordinal */
+    int32_t max_batch;  /* workspaces are sized for this many images per call */
+} ivit_config;
+
+/* ABI / build introspection (no GPU needed). */
+int         ivit_abi_version(void);
+const char* ivit_build_info(void);
+const char* ivit_last_error(void);
+
+/* Stage bookkeeping (pure host arithmetic, no GPU needed).
+ * ivit_stage_count: 6 + L.  ivit_stage_shape: per-image element shape of a stage's input
+ * (which = 0) or output (which = 1); returns ndim and writes up to 3 dims. */
+int ivit_stage_count(const ivit_config* cfg);
+int ivit_stage_shape(const ivit_config* cfg, int stage, int which, int64_t dims[3]);
+
+/* Patch bookkeeping oracle hook (host arithmetic): flat offset into a [3,S,S] image of unfold
+ * element (patch n, column k), the same function the device unfold kernel is compiled from.
+ * Replaces nothing in the reference (it has no unfold); pins "bit-exact patch index". */
+int64_t ivit_unfold_offset(int32_t image, int32_t patch, int32_t n, int32_t k);
+
+/* Lifecycle. */
+int  ivit_create(const ivit_config* cfg, ivit_engine** out);
+void ivit_destroy(ivit_engine* e);
+
+/* Weights: torchvision VisionTransformer state-dict names (see interactive_vit_amd/weights.py),
+ * float32 host arrays; converted to bf16 (matrices) / kept f32 (biases, LN, pos, cls) on device.
+ * ivit_weights_ready fails and names the first missing tensor if the set is incomplete. */
+int ivit_set_weight(ivit_engine* e, const char* name, const float* host, const int64_t* shape, int ndim);
+int ivit_weights_ready(ivit_engine* e);
+
+/* Replaces: Model.compute -> sub(x)  (reference main/context.py:79-88) for a run of nodes.
+ * Host-buffer form (interactive path: the request tensors are CPU f32, main/message.py:58):
+ * copies `in` to the device, runs stages [begin,end), copies the last stage's output to `out`.
+ * out_capacity is in floats; fails if the result does not fit. */
+int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end, int batch,
+                      const float* in, float* out, int64_t out_capacity);
+
+/* Device-pointer form (benchmark / chained nodes): `in` and `out` are device f32 buffers on the
+ * engine's device, work is enqueued on `stream` (a hipStream_t; NULL = the null stream) and the
+ * call returns without synchronising.  cls_out (optional, may be NULL) receives the [B,D] f32
+ * class-token features after encoder.ln when the range ends at or after stage 4+L. */
+int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_end, int batch,
+                        const void* in, void* out, void* cls_out, void* stream);
+
+/* Inspection entry used by the parity tests: the bf16 unfold image [B*Np, Kpad] the patch GEMM
+ * consumes, widened to f32 into `out` (device, B*Np*K floats, padding columns dropped).
+ * normalise != 0 applies the transform first (the fused path), 0 unfolds the input as is. */
+int ivit_debug_unfold(ivit_engine* e, int batch, const void* in, void* out, int normalise, void* stream);
+
+/* Per-kernel-class device timing (HIP events on the launch stream), for bench.py's roofline line.
+ * While enabled every launch of a class is bracketed by an event pair; ivit_profile_read
+ * synchronises, then returns accumulated milliseconds, launch count and algorithmic FLOPs and
+ * bytes of class `cls` since ivit_profile_reset.  Class names: ivit_profile_class_name(i). */
+int         ivit_profile_enable(ivit_engine* e, int on);
+int         ivit_profile_reset(ivit_engine* e);
+int         ivit_profile_class_count(void);
+const char* ivit_profile_class_name(int cls);
+int         ivit_profile_read(ivit_engine* e, int cls, double* ms, int64_t* launches,
+                              double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVIT_H */

@@ -1,0 +1,68 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ivit {
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // one 16x16 MFMA accumulator fragment
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define IVIT_LDS __attribute__((address_space(3)))
+#define IVIT_GLOBAL __attribute__((address_space(1)))
+
+constexpr int WAVE = 64;
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// f32 -> bf16, round to nearest even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps
+// NaN a NaN (MI355X_MICROARCH.md, correctness boundaries).
+__device__ __forceinline__ bf16_t f2bf(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) {
+    return __builtin_bit_cast(float, ((unsigned int)b) << 16);
+}
+// two f32 -> packed bf16x2 in one dword (lo in bits 0..15)
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    f2 v = {lo, hi};
+    bf2 r = __builtin_convertvector(v, bf2);
+    return __builtin_bit_cast(unsigned int, r);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// exact (erf) GELU, as torch.nn.GELU() default
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// The unfold bookkeeping, shared by host (ivit_unfold_offset) and device (unfold kernel):
+// patch n = gy*G + gx, column k = c*p*p + ky*p + kx  ->  flat offset in a [3,S,S] image.
+__host__ __device__ inline int64_t unfold_offset(int image, int patch, int n, int k) {
+    const int g = image / patch;
+    const int gy = n / g, gx = n - gy * g;
+    const int pp = patch * patch;
+    const int c = k / pp, r = k - c * pp;
+    const int ky = r / patch, kx = r - ky * patch;
+    return (int64_t)c * image * image + (int64_t)(gy * patch + ky) * image + (gx * patch + kx);
+}
+
+}  // namespace ivit

@@ -1,0 +1,560 @@
+// libivit.so - C ABI (include/ivit.h) of the MI355X ViT forward engine: handle lifecycle, weight
+// upload (f32 -> bf16 on device), stage-range forward over the hand-written gfx950 kernels, error
+// strings, per-kernel-class event timing.  Host side only; device code lives in kernels_*.hip.
+#include "../../include/ivit.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace ivit;
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local std::string t_last_error;
+
+static int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    t_last_error = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* ivit_last_error(void) { return t_last_error.c_str(); }
+extern "C" int ivit_abi_version(void) { return IVIT_ABI_VERSION; }
+extern "C" const char* ivit_build_info(void) {
+    return "libivit gfx950 (MI355X/CDNA4) bf16-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_128x128x64, ivit_attention_bf16, "
+           "ivit_layernorm, ivit_unfold, ivit_tokens, ivit_transform";
+}
+
+// ------------------------------------------------------------------------------------ stages
+enum { ST_TRANSFORM = 0, ST_CONV = 1, ST_TOKENS = 2, ST_LAYER0 = 3 };
+
+static bool config_ok(const ivit_config* c, std::string* why) {
+    auto bad = [&](const char* m) { if (why) *why = m; return false; };
+    if (!c) return bad("config is null");
+    if (c->image <= 0 || c->patch <= 0 || c->image % c->patch) return bad("image must be a positive multiple of patch");
+    if (c->image % 4) return bad("image size must be a multiple of 4");
+    if (c->dim <= 0 || c->dim % 64) return bad("dim must be a positive multiple of 64");
+    if (c->heads <= 0 || c->dim % c->heads) return bad("dim must be divisible by heads");
+    if (c->mlp <= 0 || c->mlp % 64) return bad("mlp must be a positive multiple of 64");
+    if (c->layers < 0 || c->classes <= 0 || c->max_batch <= 0) return bad("layers/classes/max_batch out of range");
+    if (c->dim > 2048) return bad("dim > 2048 unsupported");
+    return true;
+}
+
+extern "C" int ivit_stage_count(const ivit_config* cfg) { return cfg ? 6 + cfg->layers : -1; }
+
+extern "C" int ivit_stage_shape(const ivit_config* c, int stage, int which, int64_t dims[3]) {
+    if (!c || stage < 0 || stage >= 6 + c->layers || (which != 0 && which != 1)) return -1;
+    const int64_t S = c->image, g = c->image / c->patch, np = g * g, n = np + 1, d = c->dim;
+    const int L = c->layers;
+    auto set = [&](int nd, int64_t a, int64_t b, int64_t cc) { dims[0] = a; dims[1] = b; dims[2] = cc; return nd; };
+    const bool in = (which == 0);
+    if (stage == ST_TRANSFORM) return set(3, 3, S, S);
+    if (stage == ST_CONV) return in ? set(3, 3, S, S) : set(2, np, d, 0);
+    if (stage == ST_TOKENS) return in ? set(2, np, d, 0) : set(2, n, d, 0);
+    if (stage < ST_LAYER0 + L) return set(2, n, d, 0);
+    if (stage == ST_LAYER0 + L) return set(2, n, d, 0);                              // encoder.ln
+    if (stage == ST_LAYER0 + L + 1) return in ? set(2, n, d, 0) : set(1, d, 0, 0);   // cls
+    return in ? set(1, d, 0, 0) : set(1, c->classes, 0, 0);                          // heads
+}
+
+static int64_t shape_elems(const ivit_config* c, int stage, int which) {
+    int64_t d[3];
+    const int nd = ivit_stage_shape(c, stage, which, d);
+    int64_t e = 1;
+    for (int i = 0; i < nd; ++i) e *= d[i];
+    return e;
+}
+
+extern "C" int64_t ivit_unfold_offset(int32_t image, int32_t patch, int32_t n, int32_t k) {
+    return unfold_offset(image, patch, n, k);
+}
+
+// ------------------------------------------------------------------------------------ engine
+enum ProfClass { PC_GEMM = 0, PC_ATTN = 1, PC_LAYERNORM = 2, PC_OTHER = 3, PC_COUNT = 4 };
+static const char* k_prof_names[PC_COUNT] = {"gemm", "attention", "layernorm", "other"};
+
+struct Matrix {   // bf16 [rows_pad][ld], zero padded
+    bf16_t* p = nullptr;
+    int rows = 0, cols = 0, ld = 0;
+};
+struct LayerWeights {
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+    float *b_in = nullptr, *b_out = nullptr, *b1 = nullptr, *b2 = nullptr;
+    Matrix w_in, w_out, w1, w2;
+};
+
+struct ivit_engine {
+    ivit_config cfg{};
+    int G = 0, Np = 0, N = 0, K = 0, Kp = 0, D = 0, dh = 0;
+    std::mutex mu;
+    hipStream_t own_stream = nullptr;
+    std::vector<void*> allocs;
+    std::map<std::string, bool> have;
+    bool weights_complete = false;
+
+    Matrix w_patch, w_head;
+    float *b_patch = nullptr, *cls_tok = nullptr, *pos = nullptr, *lnf_g = nullptr, *lnf_b = nullptr, *b_head = nullptr;
+    std::vector<LayerWeights> layers;
+
+    // workspaces (row counts padded so that tile loads never leave the allocation)
+    bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr, *hc = nullptr;
+    float *x = nullptr, *clsf = nullptr, *ext_in = nullptr, *ext_out = nullptr, *upload = nullptr;
+    int64_t ext_elems = 0, upload_elems = 0;
+
+    // profiling
+    bool prof_on = false;
+    struct Span { hipEvent_t a, b; };
+    std::vector<Span> spans[PC_COUNT];
+    std::vector<hipEvent_t> event_pool;
+    double prof_flops[PC_COUNT] = {0, 0, 0, 0}, prof_bytes[PC_COUNT] = {0, 0, 0, 0};
+};
+
+static int dev_alloc(ivit_engine* e, void** out, size_t bytes, bool zero) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes < 16 ? 16 : bytes));
+    e->allocs.push_back(p);
+    if (zero) HIP_TRY(hipMemset(p, 0, bytes < 16 ? 16 : bytes));
+    *out = p;
+    return 0;
+}
+
+static int alloc_matrix(ivit_engine* e, Matrix* m, int rows, int cols) {
+    m->rows = rows;
+    m->cols = cols;
+    m->ld = round_up(cols, 64);
+    return dev_alloc(e, (void**)&m->p, (size_t)round_up(rows, 128) * m->ld * sizeof(bf16_t), true);
+}
+
+static int alloc_vec(ivit_engine* e, float** v, int64_t n) { return dev_alloc(e, (void**)v, (size_t)n * sizeof(float), true); }
+
+struct ProfScope {   // brackets one launch with events when profiling is on
+    ivit_engine* e; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(ivit_engine* e_, int cls_, hipStream_t s_, double flops, double bytes) : e(e_), cls(cls_), s(s_), on(e_->prof_on) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t ev = nullptr;
+            if (!e->event_pool.empty()) { ev = e->event_pool.back(); e->event_pool.pop_back(); }
+            else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+            return ev;
+        };
+        a = get(); b = get();
+        if (!a || !b) { on = false; return; }
+        e->prof_flops[cls] += flops;
+        e->prof_bytes[cls] += bytes;
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        e->spans[cls].push_back({a, b});
+    }
+};
+
+extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
+    std::string why;
+    if (!out) return fail("ivit_create: out is null");
+    *out = nullptr;
+    if (!config_ok(cfg, &why)) return fail("ivit_create: %s", why.c_str());
+    const int dh = cfg->dim / cfg->heads;
+    const int g = cfg->image / cfg->patch;
+    if (!attention_supported(g * g + 1, dh))
+        return fail("ivit_create: attention kernel supports head_dim 64 and <= 608 tokens (got head_dim %d, %d tokens)", dh, g * g + 1);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("ivit_create: device %d not present (%d visible)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    ivit_engine* e = new ivit_engine();
+    e->cfg = *cfg;
+    e->G = g; e->Np = g * g; e->N = e->Np + 1; e->D = cfg->dim; e->dh = dh;
+    e->K = 3 * cfg->patch * cfg->patch;
+    e->Kp = round_up(e->K, 64);
+    const int D = e->D, Mlp = cfg->mlp, B = cfg->max_batch;
+    int rc = 0;
+    auto chk = [&](int r) { rc |= r; };
+
+    if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); }
+    chk(alloc_matrix(e, &e->w_patch, D, e->K));
+    chk(alloc_vec(e, &e->b_patch, D));
+    chk(alloc_vec(e, &e->cls_tok, D));
+    chk(alloc_vec(e, &e->pos, (int64_t)e->N * D));
+    e->layers.resize(cfg->layers);
+    for (auto& lw : e->layers) {
+        chk(alloc_vec(e, &lw.ln1_g, D)); chk(alloc_vec(e, &lw.ln1_b, D));
+        chk(alloc_vec(e, &lw.ln2_g, D)); chk(alloc_vec(e, &lw.ln2_b, D));
+        chk(alloc_matrix(e, &lw.w_in, 3 * D, D)); chk(alloc_vec(e, &lw.b_in, 3 * D));
+        chk(alloc_matrix(e, &lw.w_out, D, D)); chk(alloc_vec(e, &lw.b_out, D));
+        chk(alloc_matrix(e, &lw.w1, Mlp, D)); chk(alloc_vec(e, &lw.b1, Mlp));
+        chk(alloc_matrix(e, &lw.w2, D, Mlp)); chk(alloc_vec(e, &lw.b2, D));
+        if (rc) break;
+    }
+    chk(alloc_vec(e, &e->lnf_g, D)); chk(alloc_vec(e, &e->lnf_b, D));
+    chk(alloc_matrix(e, &e->w_head, cfg->classes, D)); chk(alloc_vec(e, &e->b_head, cfg->classes));
+
+    const int64_t rows_tok = round_up(B * e->N, 256), rows_patch = round_up(B * e->Np, 256);
+    chk(dev_alloc(e, (void**)&e->patches, (size_t)rows_patch * e->Kp * 2, true));
+    chk(dev_alloc(e, (void**)&e->x, (size_t)rows_tok * D * 4, true));
+    chk(dev_alloc(e, (void**)&e->h, (size_t)rows_tok * D * 2, true));
+    chk(dev_alloc(e, (void**)&e->qkv, (size_t)rows_tok * 3 * D * 2, true));
+    chk(dev_alloc(e, (void**)&e->att, (size_t)rows_tok * D * 2, true));
+    chk(dev_alloc(e, (void**)&e->u, (size_t)rows_tok * Mlp * 2, true));
+    chk(dev_alloc(e, (void**)&e->hc, (size_t)round_up(B, 256) * D * 2, true));
+    chk(alloc_vec(e, &e->clsf, (int64_t)B * D));
+    int64_t per_img = 0;
+    for (int s = 0; s < 6 + cfg->layers; ++s)
+        for (int w = 0; w < 2; ++w) per_img = std::max(per_img, shape_elems(cfg, s, w));
+    e->ext_elems = per_img * B;
+    chk(alloc_vec(e, &e->ext_in, e->ext_elems));
+    chk(alloc_vec(e, &e->ext_out, e->ext_elems));
+    e->upload_elems = std::max<int64_t>((int64_t)3 * D * D, std::max<int64_t>((int64_t)Mlp * D, std::max<int64_t>((int64_t)e->N * D, (int64_t)cfg->classes * D)));
+    e->upload_elems = std::max<int64_t>(e->upload_elems, (int64_t)D * e->K);
+    chk(alloc_vec(e, &e->upload, e->upload_elems));
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail("hipDeviceSynchronize failed after allocation");
+    if (rc) { std::string msg = t_last_error; ivit_destroy(e); t_last_error = msg; return 1; }
+    *out = e;
+    return 0;
+}
+
+extern "C" void ivit_destroy(ivit_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (int c = 0; c < PC_COUNT; ++c)
+        for (auto& sp : e->spans[c]) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+// ------------------------------------------------------------------------------------ weights
+struct Slot { float* vec = nullptr; Matrix* mat = nullptr; int64_t elems = 0; int rows = 0, cols = 0; };
+
+static bool find_slot(ivit_engine* e, const std::string& name, Slot* s) {
+    const int D = e->D, Mlp = e->cfg.mlp;
+    auto vec = [&](float* p, int64_t n) { s->vec = p; s->elems = n; return true; };
+    auto mat = [&](Matrix* m) { s->mat = m; s->rows = m->rows; s->cols = m->cols; s->elems = (int64_t)m->rows * m->cols; return true; };
+    if (name == "conv_proj.weight") return mat(&e->w_patch);
+    if (name == "conv_proj.bias") return vec(e->b_patch, D);
+    if (name == "class_token") return vec(e->cls_tok, D);
+    if (name == "encoder.pos_embedding") return vec(e->pos, (int64_t)e->N * D);
+    if (name == "encoder.ln.weight") return vec(e->lnf_g, D);
+    if (name == "encoder.ln.bias") return vec(e->lnf_b, D);
+    if (name == "heads.head.weight") return mat(&e->w_head);
+    if (name == "heads.head.bias") return vec(e->b_head, e->cfg.classes);
+    const std::string pre = "encoder.layers.encoder_layer_";
+    if (name.compare(0, pre.size(), pre) != 0) return false;
+    size_t dot = name.find('.', pre.size());
+    if (dot == std::string::npos) return false;
+    int li = -1;
+    try { li = std::stoi(name.substr(pre.size(), dot - pre.size())); } catch (...) { return false; }
+    if (li < 0 || li >= (int)e->layers.size()) return false;
+    LayerWeights& lw = e->layers[li];
+    const std::string rest = name.substr(dot + 1);
+    if (rest == "ln_1.weight") return vec(lw.ln1_g, D);
+    if (rest == "ln_1.bias") return vec(lw.ln1_b, D);
+    if (rest == "ln_2.weight") return vec(lw.ln2_g, D);
+    if (rest == "ln_2.bias") return vec(lw.ln2_b, D);
+    if (rest == "self_attention.in_proj_weight") return mat(&lw.w_in);
+    if (rest == "self_attention.in_proj_bias") return vec(lw.b_in, 3 * D);
+    if (rest == "self_attention.out_proj.weight") return mat(&lw.w_out);
+    if (rest == "self_attention.out_proj.bias") return vec(lw.b_out, D);
+    if (rest == "mlp.0.weight") return mat(&lw.w1);
+    if (rest == "mlp.0.bias") return vec(lw.b1, Mlp);
+    if (rest == "mlp.3.weight") return mat(&lw.w2);
+    if (rest == "mlp.3.bias") return vec(lw.b2, D);
+    return false;
+}
+
+static std::vector<std::string> all_weight_names(ivit_engine* e) {
+    std::vector<std::string> n = {"conv_proj.weight", "conv_proj.bias", "class_token", "encoder.pos_embedding"};
+    const char* per[] = {"ln_1.weight", "ln_1.bias", "self_attention.in_proj_weight", "self_attention.in_proj_bias",
+                         "self_attention.out_proj.weight", "self_attention.out_proj.bias", "ln_2.weight", "ln_2.bias",
+                         "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"};
+    for (size_t i = 0; i < e->layers.size(); ++i)
+        for (const char* p : per) n.push_back("encoder.layers.encoder_layer_" + std::to_string(i) + "." + p);
+    n.insert(n.end(), {"encoder.ln.weight", "encoder.ln.bias", "heads.head.weight", "heads.head.bias"});
+    return n;
+}
+
+extern "C" int ivit_set_weight(ivit_engine* e, const char* name, const float* host, const int64_t* shape, int ndim) {
+    if (!e || !name || !host || (ndim > 0 && !shape)) return fail("ivit_set_weight: null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    Slot s;
+    if (!find_slot(e, name, &s)) return fail("ivit_set_weight: unknown weight '%s'", name);
+    int64_t elems = 1;
+    for (int i = 0; i < ndim; ++i) elems *= shape[i];
+    if (elems != s.elems) return fail("ivit_set_weight: '%s' has %lld elements, expected %lld", name, (long long)elems, (long long)s.elems);
+    if (s.mat && (ndim < 2 || shape[0] != s.rows)) return fail("ivit_set_weight: '%s' leading dimension must be %d", name, s.rows);
+    if (s.vec) {
+        HIP_TRY(hipMemcpy(s.vec, host, (size_t)elems * 4, hipMemcpyHostToDevice));
+    } else {
+        if (elems > e->upload_elems) return fail("ivit_set_weight: staging buffer too small for '%s'", name);
+        HIP_TRY(hipMemcpy(e->upload, host, (size_t)elems * 4, hipMemcpyHostToDevice));
+        HIP_TRY(launch_f32_to_bf16(e->upload, s.cols, s.mat->p, s.mat->ld, s.rows, s.cols, e->own_stream));
+        HIP_TRY(hipStreamSynchronize(e->own_stream));
+    }
+    e->have[name] = true;
+    e->weights_complete = false;   // re-evaluated lazily by the next forward / ivit_weights_ready
+    return 0;
+}
+
+static int require_weights(ivit_engine* e) {
+    if (e->weights_complete) return 0;
+    for (const auto& n : all_weight_names(e))
+        if (!e->have.count(n)) return fail("weights incomplete: '%s' was never set", n.c_str());
+    e->weights_complete = true;
+    return 0;
+}
+
+extern "C" int ivit_weights_ready(ivit_engine* e) {
+    if (!e) return fail("ivit_weights_ready: null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    return require_weights(e);
+}
+
+// ------------------------------------------------------------------------------------ forward
+static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, const Matrix& W, int M, const float* bias,
+                    int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, const float* rowadd = nullptr,
+                    int ldra = 0, int grp_in = 0, int grp_out = 0, int grp_off = 0) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld;
+    p.bias = bias; p.epi = epi; p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr;
+    p.rowadd = rowadd; p.ldra = ldra; p.grp_in = grp_in; p.grp_out = grp_out; p.grp_off = grp_off;
+    const bool bf_out = (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16);
+    const double flops = 2.0 * M * (double)W.rows * W.cols;
+    const double bytes = 2.0 * ((double)M * W.cols + (double)W.rows * W.cols) + (double)M * W.rows * (bf_out ? 2 : 4) +
+                         (epi == EPI_BIAS_RESID_F32 ? 4.0 * M * W.rows : 0.0);
+    ProfScope ps(e, PC_GEMM, st, flops, bytes);
+    HIP_TRY(launch_gemm(p, st));
+    return 0;
+}
+
+static int run_layernorm(ivit_engine* e, hipStream_t st, const float* x, int64_t row_stride, int rows, const float* g,
+                         const float* b, bf16_t* o16, float* o32) {
+    const int D = e->D;
+    ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)rows * D * (4.0 + (o16 ? 2.0 : 0.0) + (o32 ? 4.0 : 0.0)));
+    HIP_TRY(launch_layernorm(x, D, row_stride, rows, D, g, b, e->cfg.ln_eps, o16, D, o32, D, st));
+    return 0;
+}
+
+static int run_layer(ivit_engine* e, hipStream_t st, int li, int B) {
+    const int D = e->D, M = B * e->N, Mlp = e->cfg.mlp;
+    LayerWeights& lw = e->layers[li];
+    if (run_layernorm(e, st, e->x, 1, M, lw.ln1_g, lw.ln1_b, e->h, nullptr)) return 1;
+    if (run_gemm(e, st, e->h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, e->qkv, 3 * D)) return 1;
+    {
+        AttnParams ap{};
+        ap.qkv = e->qkv; ap.ldqkv = 3 * D; ap.out = e->att; ap.ldo = D;
+        ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh;
+        ap.scale = 1.0f / std::sqrt((float)e->dh);
+        const double flops = 4.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh;
+        ProfScope ps(e, PC_ATTN, st, flops, 2.0 * M * 4.0 * D);
+        HIP_TRY(launch_attention(ap, st));
+    }
+    if (run_gemm(e, st, e->att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, e->x, D, e->x, D)) return 1;
+    if (run_layernorm(e, st, e->x, 1, M, lw.ln2_g, lw.ln2_b, e->h, nullptr)) return 1;
+    if (run_gemm(e, st, e->h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, e->u, Mlp)) return 1;
+    if (run_gemm(e, st, e->u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, e->x, D, e->x, D)) return 1;
+    return 0;
+}
+
+static int check_range(ivit_engine* e, int begin, int end, int batch) {
+    if (!e) return fail("null engine");
+    const int ns = 6 + e->cfg.layers;
+    if (begin < 0 || end > ns || begin >= end) return fail("stage range [%d,%d) invalid (model has %d stages)", begin, end, ns);
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    return 0;
+}
+
+// caller holds e->mu and has set the device
+static int forward_locked(ivit_engine* e, int begin, int end, int B, const float* in, float* out, float* cls_out,
+                          hipStream_t st) {
+    const int L = e->cfg.layers, D = e->D, N = e->N, Np = e->Np;
+    const int ST_LN = ST_LAYER0 + L, ST_CLS = ST_LN + 1, ST_HEADS = ST_LN + 2;
+    if (require_weights(e)) return 1;
+
+    const float* cur = in;
+    bool in_x = false, patches_ready = false;
+    int s = begin;
+
+    if (s == ST_TRANSFORM) {
+        if (end == ST_TRANSFORM + 1) {
+            ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * 3 * e->cfg.image * e->cfg.image);
+            HIP_TRY(launch_transform(cur, out, B, e->cfg.image, st));
+            return 0;
+        }
+        {
+            ProfScope ps(e, PC_OTHER, st, 0.0, 4.0 * B * 3 * e->cfg.image * e->cfg.image + 2.0 * B * Np * e->Kp);
+            HIP_TRY(launch_unfold(cur, e->patches, B, e->cfg.image, e->cfg.patch, e->Kp, 1, st));
+        }
+        patches_ready = true;
+        s = ST_CONV;
+    }
+    if (s == ST_CONV) {
+        if (!patches_ready) {
+            ProfScope ps(e, PC_OTHER, st, 0.0, 4.0 * B * 3 * e->cfg.image * e->cfg.image + 2.0 * B * Np * e->Kp);
+            HIP_TRY(launch_unfold(cur, e->patches, B, e->cfg.image, e->cfg.patch, e->Kp, 0, st));
+        }
+        if (end == ST_CONV + 1)
+            return run_gemm(e, st, e->patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_F32, out, D);
+        // conv_proj + tokens fused: the GEMM epilogue scatters rows to token 1+n of each image and adds
+        // the position embedding; a small kernel writes the class rows
+        if (run_gemm(e, st, e->patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_ROWADD_F32,
+                     (end == ST_TOKENS + 1) ? out : e->x, D, nullptr, 0, e->pos, D, Np, N, 1)) return 1;
+        {
+            ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * D);
+            HIP_TRY(launch_tokens(nullptr, e->cls_tok, e->pos, (end == ST_TOKENS + 1) ? out : e->x, B, Np, D, st));
+        }
+        if (end == ST_TOKENS + 1) return 0;
+        in_x = true;
+        s = ST_LAYER0;
+    }
+    if (s == ST_TOKENS) {
+        float* dst = (end == ST_TOKENS + 1) ? out : e->x;
+        {
+            ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * N * D);
+            HIP_TRY(launch_tokens(cur, e->cls_tok, e->pos, dst, B, Np, D, st));
+        }
+        if (end == ST_TOKENS + 1) return 0;
+        in_x = true;
+        s = ST_LAYER0;
+    }
+    for (; s < end && s < ST_LN; ++s) {
+        if (!in_x) {
+            HIP_TRY(hipMemcpyAsync(e->x, cur, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
+            in_x = true;
+        }
+        if (run_layer(e, st, s - ST_LAYER0, B)) return 1;
+    }
+    if (s >= end) {   // the range ended on an encoder layer: hand the residual stream out
+        HIP_TRY(hipMemcpyAsync(out, e->x, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    if (s == ST_LN) {
+        const float* src = in_x ? e->x : cur;
+        if (end == ST_LN + 1) return run_layernorm(e, st, src, 1, B * N, e->lnf_g, e->lnf_b, nullptr, out);
+        // only the class rows are consumed downstream: normalise B rows (stride N)
+        float* feat = (end == ST_CLS + 1) ? out : (cls_out ? cls_out : e->clsf);
+        if (run_layernorm(e, st, src, N, B, e->lnf_g, e->lnf_b, e->hc, feat)) return 1;
+        if (end == ST_CLS + 1) {
+            if (cls_out) HIP_TRY(hipMemcpyAsync(cls_out, out, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+            return 0;
+        }
+        return run_gemm(e, st, e->hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes);
+    }
+    if (s == ST_CLS) {
+        float* dst = (end == ST_CLS + 1) ? out : e->clsf;
+        {
+            ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * D);
+            HIP_TRY(launch_gather_rows(cur, N, dst, B, D, st));
+        }
+        if (cls_out) HIP_TRY(hipMemcpyAsync(cls_out, dst, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+        if (end == ST_CLS + 1) return 0;
+        cur = dst;
+        s = ST_HEADS;
+    }
+    // heads on an f32 [B,D] input
+    {
+        ProfScope ps(e, PC_OTHER, st, 0.0, 6.0 * B * D);
+        HIP_TRY(launch_f32_to_bf16(cur, D, e->hc, D, B, D, st));
+    }
+    return run_gemm(e, st, e->hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes);
+}
+
+extern "C" int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_end, int batch, const void* in, void* out,
+                                   void* cls_out, void* stream) {
+    if (check_range(e, stage_begin, stage_end, batch)) return 1;
+    if (!in || !out) return fail("ivit_forward_device: null buffer");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    return forward_locked(e, stage_begin, stage_end, batch, (const float*)in, (float*)out, (float*)cls_out, (hipStream_t)stream);
+}
+
+extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end, int batch, const float* in, float* out,
+                                 int64_t out_capacity) {
+    if (check_range(e, stage_begin, stage_end, batch)) return 1;
+    if (!in || !out) return fail("ivit_forward_host: null buffer");
+    const int64_t n_in = shape_elems(&e->cfg, stage_begin, 0) * batch;
+    const int64_t n_out = shape_elems(&e->cfg, stage_end - 1, 1) * batch;
+    if (n_out > out_capacity) return fail("ivit_forward_host: output needs %lld floats, capacity is %lld", (long long)n_out, (long long)out_capacity);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->own_stream;
+    HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
+    if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int ivit_debug_unfold(ivit_engine* e, int batch, const void* in, void* out, int normalise, void* stream) {
+    if (!e || !in || !out) return fail("ivit_debug_unfold: null argument");
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d", batch, e->cfg.max_batch);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(launch_unfold((const float*)in, e->patches, batch, e->cfg.image, e->cfg.patch, e->Kp, normalise ? 1 : 0, st));
+    HIP_TRY(launch_bf16_to_f32(e->patches, e->Kp, (float*)out, batch * e->Np, e->K, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ profiling
+extern "C" int ivit_profile_class_count(void) { return PC_COUNT; }
+extern "C" const char* ivit_profile_class_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? k_prof_names[cls] : ""; }
+
+extern "C" int ivit_profile_enable(ivit_engine* e, int on) {
+    if (!e) return fail("null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int ivit_profile_reset(ivit_engine* e) {
+    if (!e) return fail("null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (int c = 0; c < PC_COUNT; ++c) {
+        for (auto& sp : e->spans[c]) { e->event_pool.push_back(sp.a); e->event_pool.push_back(sp.b); }
+        e->spans[c].clear();
+        e->prof_flops[c] = e->prof_bytes[c] = 0.0;
+    }
+    return 0;
+}
+
+extern "C" int ivit_profile_read(ivit_engine* e, int cls, double* ms, int64_t* launches, double* flops, double* bytes) {
+    if (!e || cls < 0 || cls >= PC_COUNT) return fail("ivit_profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    double total = 0.0;
+    for (auto& sp : e->spans[cls]) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
+        total += t;
+    }
+    if (ms) *ms = total;
+    if (launches) *launches = (int64_t)e->spans[cls].size();
+    if (flops) *flops = e->prof_flops[cls];
+    if (bytes) *bytes = e->prof_bytes[cls];
+    return 0;
+}

@@ -1,0 +1,62 @@
+// Launchers of the gfx950 kernels (one translation unit each); called only by engine.hip.
+#pragma once
+#include "common.h"
+
+namespace ivit {
+
+// ---------------------------------------------------------------- GEMM (kernels_gemm.hip)
+enum GemmEpilogue : int {
+    EPI_BIAS_BF16 = 0,       // out(bf16)  = acc + bias
+    EPI_BIAS_GELU_BF16 = 1,  // out(bf16)  = gelu_erf(acc + bias)
+    EPI_BIAS_RESID_F32 = 2,  // out(f32)   = resid + (acc + bias)          (out may alias resid)
+    EPI_BIAS_F32 = 3,        // out(f32)   = acc + bias
+    EPI_BIAS_ROWADD_F32 = 4, // out(f32)[remap(m)] = (acc + bias) + rowadd[grp_off + m % grp_in]
+};
+
+struct GemmParams {
+    const bf16_t* A; int lda;     // [M, K] bf16 row-major, rows readable up to round_up(M,128)
+    const bf16_t* W; int ldw;     // [N, K] bf16 row-major, rows readable up to round_up(N,128)
+    int M, N, K;                  // K % 64 == 0 (operands zero-padded)
+    const float* bias;            // [N]
+    int epi;
+    void* out; int ldo;
+    const float* resid; int ldr;  // EPI_BIAS_RESID_F32
+    const float* rowadd; int ldra;  // EPI_BIAS_ROWADD_F32: [grp_out, N] table (position embedding)
+    int grp_in, grp_out, grp_off;   // row remap m -> (m / grp_in) * grp_out + grp_off + m % grp_in
+};
+
+hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
+const char* gemm_kernel_name();
+
+// ---------------------------------------------------------------- attention (kernels_attn.hip)
+struct AttnParams {
+    const bf16_t* qkv; int ldqkv;  // [B*N, 3D] bf16: q | k | v, head h at columns h*dh
+    bf16_t* out; int ldo;          // [B*N, D] bf16
+    int batch, tokens, heads, head_dim;
+    float scale;                   // 1/sqrt(dh)
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+bool attention_supported(int tokens, int head_dim);
+
+// ---------------------------------------------------------------- misc (kernels_misc.hip)
+// (x - mean[c]) / std[c] on [B,3,S,S] f32
+hipError_t launch_transform(const float* in, float* out, int batch, int image, hipStream_t s);
+// f32 image -> bf16 unfold matrix [B*Np, kpad] (columns >= 3p^2 zero); normalise fuses the transform
+hipError_t launch_unfold(const float* in, bf16_t* out, int batch, int image, int patch, int kpad,
+                         int normalise, hipStream_t s);
+// out[b,0,:] = cls + pos[0]; out[b,1+n,:] = in[b,n,:] + pos[1+n]   (in == nullptr: class rows only)
+hipError_t launch_tokens(const float* in, const float* cls, const float* pos, float* out, int batch,
+                         int patches, int dim, hipStream_t s);
+// LayerNorm over the last dim of rows `row0 + i*row_stride` (i < rows) of a [*, dim] f32 matrix;
+// writes bf16 (out_bf16, ld = ldo16) and/or f32 (out_f32, ld = ldo32) at row i.
+hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int rows, int dim, const float* gamma,
+                            const float* beta, float eps, bf16_t* out_bf16, int ldo16, float* out_f32,
+                            int ldo32, hipStream_t s);
+// strided row gather: out[i,:] = in[i*row_stride, :dim]  (the `cls` node)
+hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, int rows, int dim, hipStream_t s);
+// f32 [rows, cols] -> bf16 [rows, ldo] (columns >= cols zero)
+hipError_t launch_f32_to_bf16(const float* in, int ldi, bf16_t* out, int ldo, int rows, int cols, hipStream_t s);
+// bf16 [rows, ldi] -> f32 [rows, cols]
+hipError_t launch_bf16_to_f32(const bf16_t* in, int ldi, float* out, int rows, int cols, hipStream_t s);
+
+}  // namespace ivit

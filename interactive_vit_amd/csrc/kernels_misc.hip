@@ -1,0 +1,250 @@
+// HBM-bound glue kernels of the ViT forward: image normalisation, unfold (im2col) to bf16,
+// class-token / position-embedding assembly, LayerNorm (wavefront-shuffle reductions), row gather
+// and dtype conversion.  All are coalesced 16-B-per-lane streams; none is reshaped into a GEMM.
+#include "kernels.h"
+
+namespace ivit {
+
+__constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
+__constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
+
+constexpr int EW_THREADS = 256;
+static inline int ew_grid(int64_t work_items) {
+    int64_t blocks = (work_items + EW_THREADS - 1) / EW_THREADS;
+    return (int)(blocks < 1 ? 1 : (blocks > 2048 * 4 ? 2048 * 4 : blocks));  // grid-stride beyond that
+}
+
+// ---------------------------------------------------------------------------- transform
+__global__ void ivit_transform(const float* __restrict__ in, float* __restrict__ out, int64_t total, int plane) {
+    // total = B*3*S*S, plane = S*S (multiple of 4 for every supported S)
+    const int64_t n4 = total >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(((i << 2) / plane) % 3);
+        const float m = c_mean[c], s = c_std[c];
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        v.x = (v.x - m) / s; v.y = (v.y - m) / s; v.z = (v.z - m) / s; v.w = (v.w - m) / s;
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+    const int64_t tail = n4 << 2;   // plane % 4 != 0 only for exotic sizes
+    for (int64_t i = tail + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / plane) % 3);
+        out[i] = (in[i] - c_mean[c]) / c_std[c];
+    }
+}
+
+hipError_t launch_transform(const float* in, float* out, int batch, int image, hipStream_t s) {
+    const int64_t total = (int64_t)batch * 3 * image * image;
+    hipLaunchKernelGGL(ivit_transform, dim3(ew_grid(total / 4 + 1)), dim3(EW_THREADS), 0, s, in, out, total, image * image);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------- unfold (im2col)
+// One thread produces 8 consecutive k of one patch row n: 16 B of bf16.  For p % 8 == 0 the 8
+// sources are 8 consecutive pixels of one image row (two float4 loads); otherwise each element is
+// located through unfold_offset().  Columns k >= 3p^2 (K padding up to a multiple of 64) are zero.
+__global__ void ivit_unfold(const float* __restrict__ in, bf16_t* __restrict__ out, int batch, int image,
+                            int patch, int kpad, int normalise) {
+    const int g = image / patch;
+    const int np = g * g;
+    const int kreal = 3 * patch * patch;
+    const int kchunks = kpad >> 3;
+    const int64_t total = (int64_t)batch * np * kchunks;
+    const int64_t img_elems = (int64_t)3 * image * image;
+    const int pp = patch * patch;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(i % kchunks);
+        const int64_t row = i / kchunks;            // b*Np + n
+        const int n = (int)(row % np);
+        const int b = (int)(row / np);
+        const float* img = in + b * img_elems;
+        const int k0 = kc * 8;
+        float v[8];
+        if ((patch & 7) == 0 && k0 + 8 <= kreal) {
+            const float* src = img + unfold_offset(image, patch, n, k0);
+            const float4 lo = *reinterpret_cast<const float4*>(src);
+            const float4 hi = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            if (normalise) {
+                const int c = k0 / pp;
+                const float m = c_mean[c], s = c_std[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] - m) / s;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                float x = 0.f;
+                if (k < kreal) {
+                    x = img[unfold_offset(image, patch, n, k)];
+                    if (normalise) { const int c = k / pp; x = (x - c_mean[c]) / c_std[c]; }
+                }
+                v[e] = x;
+            }
+        }
+        u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        *reinterpret_cast<u32x4*>(out + row * kpad + k0) = pk;
+    }
+}
+
+hipError_t launch_unfold(const float* in, bf16_t* out, int batch, int image, int patch, int kpad, int normalise,
+                         hipStream_t s) {
+    const int g = image / patch;
+    const int64_t total = (int64_t)batch * g * g * (kpad / 8);
+    hipLaunchKernelGGL(ivit_unfold, dim3(ew_grid(total)), dim3(EW_THREADS), 0, s, in, out, batch, image, patch, kpad, normalise);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------- tokens
+__global__ void ivit_tokens(const float* __restrict__ in, const float* __restrict__ cls, const float* __restrict__ pos,
+                            float* __restrict__ out, int batch, int patches, int dim) {
+    const int d4 = dim >> 2;
+    const int N = patches + 1;
+    const int rows_per_img = in ? N : 1;
+    const int64_t total = (int64_t)batch * rows_per_img * d4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d4);
+        const int64_t r = i / d4;
+        const int t = (int)(r % rows_per_img);
+        const int b = (int)(r / rows_per_img);
+        const float4 pe = reinterpret_cast<const float4*>(pos + (size_t)t * dim)[c];
+        float4 v;
+        if (t == 0) v = reinterpret_cast<const float4*>(cls)[c];
+        else v = reinterpret_cast<const float4*>(in + ((size_t)b * patches + (t - 1)) * dim)[c];
+        v.x += pe.x; v.y += pe.y; v.z += pe.z; v.w += pe.w;
+        reinterpret_cast<float4*>(out + ((size_t)b * N + t) * dim)[c] = v;
+    }
+}
+
+hipError_t launch_tokens(const float* in, const float* cls, const float* pos, float* out, int batch, int patches,
+                         int dim, hipStream_t s) {
+    if (dim % 4) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)batch * (in ? patches + 1 : 1) * (dim / 4);
+    hipLaunchKernelGGL(ivit_tokens, dim3(ew_grid(total)), dim3(EW_THREADS), 0, s, in, cls, pos, out, batch, patches, dim);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------- LayerNorm
+// One wavefront per row; the row (dim <= 64*4*VPL floats) stays in registers between the two
+// statistics passes (mean, then centred variance - the same two-pass form as the oracle), so x is
+// read from HBM once.  Reductions are 64-lane xor-shuffles.
+template <int VPL>  // float4 vectors per lane
+__global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ x, int ldx, int64_t row_stride, int rows,
+                                                      int dim, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps,
+                                                      bf16_t* __restrict__ o16, int ldo16, float* __restrict__ o32,
+                                                      int ldo32) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * row_stride * ldx;
+    const int d4 = dim >> 2;
+    float4 v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = (c < d4) ? reinterpret_cast<const float4*>(xr)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < d4) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < d4) {
+            const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
+            const float4 bt = reinterpret_cast<const float4*>(beta)[c];
+            float4 y;
+            y.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+            y.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+            y.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+            y.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+            if (o32) reinterpret_cast<float4*>(o32 + (size_t)row * ldo32)[c] = y;
+            if (o16) {
+                u32x2 pk = {pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
+                reinterpret_cast<u32x2*>(o16 + (size_t)row * ldo16)[c] = pk;
+            }
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int rows, int dim, const float* gamma,
+                            const float* beta, float eps, bf16_t* o16, int ldo16, float* o32, int ldo32,
+                            hipStream_t s) {
+    if (dim % 4 || dim > 64 * 4 * 8) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    const dim3 grid(ceil_div(rows, 4)), block(256);
+    const int vpl = ceil_div(dim / 4, 64);
+#define IVIT_LN(V) hipLaunchKernelGGL(ivit_layernorm<V>, grid, block, 0, s, x, ldx, row_stride, rows, dim, gamma, beta, eps, o16, ldo16, o32, ldo32)
+    if (vpl <= 1) IVIT_LN(1);
+    else if (vpl <= 2) IVIT_LN(2);
+    else if (vpl <= 3) IVIT_LN(3);
+    else if (vpl <= 4) IVIT_LN(4);
+    else if (vpl <= 5) IVIT_LN(5);
+    else IVIT_LN(8);
+#undef IVIT_LN
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------- gather / convert
+__global__ void ivit_gather_rows(const float* __restrict__ in, int64_t row_stride, float* __restrict__ out, int rows, int dim) {
+    const int d4 = dim >> 2;
+    const int64_t total = (int64_t)rows * d4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d4);
+        const int64_t r = i / d4;
+        reinterpret_cast<float4*>(out + r * dim)[c] = reinterpret_cast<const float4*>(in + r * row_stride * dim)[c];
+    }
+}
+
+hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, int rows, int dim, hipStream_t s) {
+    if (dim % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivit_gather_rows, dim3(ew_grid((int64_t)rows * dim / 4)), dim3(EW_THREADS), 0, s, in, row_stride, out, rows, dim);
+    return hipGetLastError();
+}
+
+__global__ void ivit_f32_to_bf16(const float* __restrict__ in, int ldi, bf16_t* __restrict__ out, int ldo, int rows, int cols) {
+    const int c4 = ldo >> 2;   // output is written over the full padded width
+    const int64_t total = (int64_t)rows * c4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4) * 4;
+        const int64_t r = i / c4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (c + e < cols) ? in[r * ldi + c + e] : 0.f;
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(out + r * ldo + c) = pk;
+    }
+}
+
+hipError_t launch_f32_to_bf16(const float* in, int ldi, bf16_t* out, int ldo, int rows, int cols, hipStream_t s) {
+    if (ldo % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivit_f32_to_bf16, dim3(ew_grid((int64_t)rows * ldo / 4)), dim3(EW_THREADS), 0, s, in, ldi, out, ldo, rows, cols);
+    return hipGetLastError();
+}
+
+__global__ void ivit_bf16_to_f32(const bf16_t* __restrict__ in, int ldi, float* __restrict__ out, int rows, int cols) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols);
+        const int64_t r = i / cols;
+        out[i] = bf2f(in[r * ldi + c]);
+    }
+}
+
+hipError_t launch_bf16_to_f32(const bf16_t* in, int ldi, float* out, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(ivit_bf16_to_f32, dim3(ew_grid((int64_t)rows * cols)), dim3(EW_THREADS), 0, s, in, ldi, out, rows, cols);
+    return hipGetLastError();
+}
+
+}  // namespace ivit

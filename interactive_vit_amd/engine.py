@@ -1,0 +1,237 @@
+"""ctypes binding of the C ABI in ``include/ivit.h`` (libivit.so: hand-written gfx950 kernels).
+
+There is no CPU or eager-PyTorch fallback: if the shared library is missing, fails to load, or an
+entry point is absent, construction raises.  torch is used for device memory and streams only -
+tensors cross the ABI as raw ``data_ptr()`` addresses.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .vit_config import VitConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libivit.so")
+
+# every symbol include/ivit.h declares (tests check the built library exports each one)
+ABI_SYMBOLS = (
+    "ivit_abi_version", "ivit_build_info", "ivit_last_error", "ivit_stage_count", "ivit_stage_shape",
+    "ivit_unfold_offset", "ivit_create", "ivit_destroy", "ivit_set_weight", "ivit_weights_ready",
+    "ivit_forward_host", "ivit_forward_device", "ivit_debug_unfold", "ivit_profile_enable",
+    "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
+)
+
+
+class IvitConfigC(ctypes.Structure):
+    _fields_ = [("image", ctypes.c_int32), ("patch", ctypes.c_int32), ("dim", ctypes.c_int32),
+                ("heads", ctypes.c_int32), ("layers", ctypes.c_int32), ("mlp", ctypes.c_int32),
+                ("classes", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("device", ctypes.c_int32),
+                ("max_batch", ctypes.c_int32)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """Loads libivit.so (once).  Raises if it is absent - the product path has no fallback."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or os.environ.get("IVIT_LIB", LIB_PATH)
+        if not os.path.exists(p):
+            raise RuntimeError(
+                f"libivit.so not found at {p}: build it with `python -m interactive_vit_amd.build` "
+                "(hipcc, gfx950).  The ViT operators have no CPU fallback.")
+        lib = ctypes.CDLL(p)
+        for sym in ABI_SYMBOLS:
+            if not hasattr(lib, sym):
+                raise RuntimeError(f"{p} does not export {sym}")
+        c_i, c_p, c_i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_int64
+        cfgp = ctypes.POINTER(IvitConfigC)
+        lib.ivit_abi_version.restype = c_i
+        lib.ivit_build_info.restype = ctypes.c_char_p
+        lib.ivit_last_error.restype = ctypes.c_char_p
+        lib.ivit_stage_count.argtypes = [cfgp]
+        lib.ivit_stage_shape.argtypes = [cfgp, c_i, c_i, ctypes.POINTER(c_i64)]
+        lib.ivit_unfold_offset.argtypes = [ctypes.c_int32] * 4
+        lib.ivit_unfold_offset.restype = c_i64
+        lib.ivit_create.argtypes = [cfgp, ctypes.POINTER(c_p)]
+        lib.ivit_destroy.argtypes = [c_p]
+        lib.ivit_destroy.restype = None
+        lib.ivit_set_weight.argtypes = [c_p, ctypes.c_char_p, c_p, ctypes.POINTER(c_i64), c_i]
+        lib.ivit_weights_ready.argtypes = [c_p]
+        lib.ivit_forward_host.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64]
+        lib.ivit_forward_device.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
+        lib.ivit_debug_unfold.argtypes = [c_p, c_i, c_p, c_p, c_i, c_p]
+        lib.ivit_profile_enable.argtypes = [c_p, c_i]
+        lib.ivit_profile_reset.argtypes = [c_p]
+        lib.ivit_profile_class_name.argtypes = [c_i]
+        lib.ivit_profile_class_name.restype = ctypes.c_char_p
+        lib.ivit_profile_read.argtypes = [c_p, c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
+                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        if path is None:
+            _lib = lib
+        return lib
+
+
+class EngineError(Exception):
+    """A non-zero return from libivit; str(e) is ivit_last_error() (-> HTTP 400 body, views.py:40-42)."""
+
+
+def _config_c(cfg: VitConfig, device: int = 0, max_batch: int = 1) -> IvitConfigC:
+    return IvitConfigC(cfg.image, cfg.patch, cfg.dim, cfg.heads, cfg.layers, cfg.mlp, cfg.classes,
+                       cfg.ln_eps, device, max_batch)
+
+
+def stage_names(cfg: VitConfig) -> List[str]:
+    """Stage index -> node suffix (the order of include/ivit.h)."""
+    return (["transform", "conv_proj", "tokens"] + [f"encoder.layers.{i}" for i in range(cfg.layers)]
+            + ["encoder.ln", "cls", "heads"])
+
+
+def stage_shape(cfg: VitConfig, stage: int, which: int) -> Tuple[int, ...]:
+    """Per-image input (which=0) / output (which=1) shape of a stage, from the library's own table."""
+    lib = load_library()
+    c = _config_c(cfg)
+    dims = (ctypes.c_int64 * 3)()
+    nd = lib.ivit_stage_shape(ctypes.byref(c), stage, which, dims)
+    if nd < 0:
+        raise EngineError(f"stage {stage} out of range")
+    return tuple(int(dims[i]) for i in range(nd))
+
+
+def unfold_offset(image: int, patch: int, n: int, k: int) -> int:
+    return int(load_library().ivit_unfold_offset(image, patch, n, k))
+
+
+class Engine:
+    """One ViT engine instance bound to one GPU (owns bf16 weights + workspaces on that device)."""
+
+    def __init__(self, cfg: VitConfig, state_dict: Dict[str, torch.Tensor], device: int = 0, max_batch: int = 1):
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = int(device)
+        self.max_batch = int(max_batch)
+        self.stages = stage_names(cfg)
+        self._h = ctypes.c_void_p()
+        c = _config_c(cfg, self.device, self.max_batch)
+        self._check(self.lib.ivit_create(ctypes.byref(c), ctypes.byref(self._h)))
+        try:
+            for name, t in state_dict.items():
+                self.set_weight(name, t)
+            self._check(self.lib.ivit_weights_ready(self._h))
+        except Exception:
+            self.close()
+            raise
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise EngineError(self.lib.ivit_last_error().decode("utf-8", "replace"))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ivit_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weight(self, name: str, t: torch.Tensor) -> None:
+        t = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+        shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+        self._check(self.lib.ivit_set_weight(self._h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()))
+
+    # -- shapes --------------------------------------------------------------------------------
+    def stage_index(self, suffix: str) -> int:
+        return self.stages.index(suffix)
+
+    def in_shape(self, stage: int) -> Tuple[int, ...]:
+        return stage_shape(self.cfg, stage, 0)
+
+    def out_shape(self, stage: int) -> Tuple[int, ...]:
+        return stage_shape(self.cfg, stage, 1)
+
+    def _split_batch(self, x: torch.Tensor, stage: int) -> Tuple[int, bool]:
+        want = self.in_shape(stage)
+        if tuple(x.shape) == want:
+            return 1, False
+        if x.dim() == len(want) + 1 and tuple(x.shape[1:]) == want:
+            return int(x.shape[0]), True
+        raise EngineError(f"{self.cfg.name}:{self.stages[stage]} expects input {list(want)} "
+                          f"(optionally with a leading batch axis), got {list(x.shape)}")
+
+    # -- forward -------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, begin: int, end: int, want_cls: bool = False):
+        """Runs stages [begin, end).  CPU input -> CPU f32 output (host path); CUDA input -> CUDA
+        f32 output on the current torch stream (device path, asynchronous)."""
+        batch, batched = self._split_batch(x, begin)
+        oshape = self.out_shape(end - 1)
+        full = ((batch,) + oshape) if batched else oshape
+        if x.device.type == "cpu":
+            xin = x.detach().to(torch.float32).contiguous()
+            out = torch.empty(full, dtype=torch.float32)
+            self._check(self.lib.ivit_forward_host(self._h, begin, end, batch, ctypes.c_void_p(xin.data_ptr()),
+                                                   ctypes.c_void_p(out.data_ptr()), out.numel()))
+            return out
+        if x.device.type != "cuda" or (x.device.index or 0) != self.device:
+            raise EngineError(f"input lives on {x.device}, engine on cuda:{self.device}")
+        xin = x.detach().to(torch.float32).contiguous()
+        out = torch.empty(full, dtype=torch.float32, device=x.device)
+        cls = torch.empty((batch, self.cfg.dim), dtype=torch.float32, device=x.device) if want_cls else None
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        self._check(self.lib.ivit_forward_device(self._h, begin, end, batch, ctypes.c_void_p(xin.data_ptr()),
+                                                 ctypes.c_void_p(out.data_ptr()),
+                                                 ctypes.c_void_p(cls.data_ptr()) if want_cls else None,
+                                                 ctypes.c_void_p(stream)))
+        return (out, cls) if want_cls else out
+
+    def forward_into(self, x: torch.Tensor, out: torch.Tensor, cls: Optional[torch.Tensor], batch: int,
+                     begin: int, end: int, stream: int) -> None:
+        """Zero-overhead device call for the benchmark loop: preallocated buffers, explicit stream."""
+        self._check(self.lib.ivit_forward_device(self._h, begin, end, batch, ctypes.c_void_p(x.data_ptr()),
+                                                 ctypes.c_void_p(out.data_ptr()),
+                                                 ctypes.c_void_p(cls.data_ptr()) if cls is not None else None,
+                                                 ctypes.c_void_p(stream)))
+
+    def run_node(self, suffix: str, x: torch.Tensor) -> torch.Tensor:
+        if suffix == "forward":
+            return self.forward(x, 0, len(self.stages))
+        s = self.stage_index(suffix)
+        return self.forward(x, s, s + 1)
+
+    def debug_unfold(self, x: torch.Tensor, normalise: bool) -> torch.Tensor:
+        """bf16 unfold image the patch GEMM consumes, as f32 [B*Np, K] (parity-test inspection)."""
+        batch, _ = self._split_batch(x, 0)
+        xin = x.detach().to(torch.float32).contiguous()
+        out = torch.empty((batch * self.cfg.patches, self.cfg.patch_k), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        self._check(self.lib.ivit_debug_unfold(self._h, batch, ctypes.c_void_p(xin.data_ptr()),
+                                               ctypes.c_void_p(out.data_ptr()), int(normalise), ctypes.c_void_p(stream)))
+        return out
+
+    # -- profiling -----------------------------------------------------------------------------
+    def profile(self, on: bool) -> None:
+        self._check(self.lib.ivit_profile_enable(self._h, int(on)))
+
+    def profile_reset(self) -> None:
+        self._check(self.lib.ivit_profile_reset(self._h))
+
+    def profile_read(self) -> Dict[str, Dict[str, float]]:
+        res = {}
+        for c in range(self.lib.ivit_profile_class_count()):
+            ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            self._check(self.lib.ivit_profile_read(self._h, c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
+            res[self.lib.ivit_profile_class_name(c).decode()] = {
+                "ms": ms.value, "launches": int(n.value), "flops": fl.value, "bytes": by.value}
+        return res

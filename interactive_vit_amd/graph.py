@@ -1,0 +1,175 @@
+"""Server-side dataflow graph: the tensor container and scheduling order of one /compute request.
+
+Restates the observable behaviour of the reference's ``main/graph.py`` (Node :6-36, Port :39-43,
+Edge :46-53, Graph :55-121, Pinout :123-132) so that operator plugins written against the
+reference run unchanged here, and vice versa.  Behaviours that callers can observe and that are
+therefore preserved exactly (each is pinned by tests/golden fixtures generated from the reference):
+
+* ``Graph.add_node`` gives a node the index of its position in the request JSON (ref :59-62).
+* ``Graph.connect`` stores ONE edge per (node, out-channel); a second consumer of the same channel
+  replaces the first in ``outputs`` (ref :68) - the fan-out quirk of SURVEY A.4-1 is kept, not fixed.
+* ``Graph.order`` is the reference's worklist schedule (ref :79-99): take from the END of the
+  worklist, a node is ready when every wired input's producer has been emitted, otherwise it is
+  re-queued at the FRONT.  chain 0..5 -> [0..5]; diamond 0->{1,2}->3 plus isolated 4 -> [4,0,2,1,3].
+* ``Node.set_pinout`` fills an existing out-edge or creates a dangling one (ref :22-29).
+* ``Node.get_pinin`` / ``get_pinout`` assert that every edge carries a tensor (ref :15-20, :31-36).
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Dict, Iterable, List, Optional
+from urllib.parse import urlencode
+
+import torch
+
+__all__ = ["Node", "Port", "Edge", "Graph", "Pinout"]
+
+
+class Pinout:
+    """channel name -> tensor, for one side (all inputs or all outputs) of one node."""
+
+    def __init__(self, items: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        self.pinout: Dict[str, torch.Tensor] = dict(items) if items else {}
+
+    def set(self, ch: str, t: torch.Tensor) -> None:
+        self.pinout[ch] = t
+
+    def get(self, ch: str) -> Optional[torch.Tensor]:
+        return self.pinout.get(ch)
+
+    def __repr__(self) -> str:  # debugging aid only
+        shapes = {k: tuple(v.shape) for k, v in self.pinout.items()}
+        return f"Pinout({shapes})"
+
+
+class Port:
+    """One end of an edge: (node, channel, 'in'|'out')."""
+
+    __slots__ = ("node", "channel", "direction")
+
+    def __init__(self, node: "Node", channel: str, direction: str) -> None:
+        self.node = node
+        self.channel = channel
+        self.direction = direction
+
+
+class Edge:
+    """Carries the tensor between a producing 'out' port and a consuming 'in' port.
+
+    ``input`` is the producer side (None for a tensor shipped in the request), ``output`` the
+    consumer side (None for a dangling result) - the reference's field names (ref :51-52).
+    """
+
+    __slots__ = ("input", "output", "tensor")
+
+    def __init__(self, src: Optional[Port], tgt: Optional[Port]) -> None:
+        assert src is None or src.direction == "out"
+        assert tgt is None or tgt.direction == "in"
+        self.input = src
+        self.output = tgt
+        self.tensor: Optional[torch.Tensor] = None
+
+
+class Node:
+    def __init__(self, name: str, params: Dict[str, str], index: int) -> None:
+        self.name = name
+        self.params = params
+        self.index = index
+        self.inputs: Dict[str, Edge] = {}
+        self.outputs: Dict[str, Edge] = {}
+
+    def _collect(self, edges: Dict[str, Edge]) -> Pinout:
+        res = Pinout()
+        for ch, e in edges.items():
+            assert e.tensor is not None
+            res.set(ch, e.tensor)
+        return res
+
+    def get_pinin(self) -> Pinout:
+        return self._collect(self.inputs)
+
+    def get_pinout(self) -> Pinout:
+        return self._collect(self.outputs)
+
+    def set_pinout(self, pinout: Pinout) -> None:
+        for ch, t in pinout.pinout.items():
+            edge = self.outputs.get(ch)
+            if edge is None:
+                edge = Edge(Port(self, ch, "out"), None)
+                self.outputs[ch] = edge
+            edge.tensor = t
+
+    def _label(self) -> str:
+        return self.name + "?" + urlencode(self.params)
+
+
+class Graph:
+    def __init__(self) -> None:
+        self.nodes: List[Node] = []
+
+    def add_node(self, name: str, params: Dict[str, str]) -> Node:
+        node = Node(name, params, len(self.nodes))
+        self.nodes.append(node)
+        return node
+
+    def connect(self, a: Node, a_ch: str, b: Node, b_ch: str) -> Edge:
+        edge = Edge(Port(a, a_ch, "out"), Port(b, b_ch, "in"))
+        a.outputs[a_ch] = edge  # newest consumer wins: reference fan-out quirk, kept on purpose
+        b.inputs[b_ch] = edge
+        return edge
+
+    def add_input(self, value: torch.Tensor, node: Node, channel: str) -> Edge:
+        edge = Edge(None, Port(node, channel, "in"))
+        edge.tensor = value
+        node.inputs[channel] = edge
+        return edge
+
+    @staticmethod
+    def _ready(node: Node, done: set) -> bool:
+        return all(e.input is None or e.input.node in done for e in node.inputs.values())
+
+    def order(self) -> List[Node]:
+        """Reference schedule (main/graph.py:79-99); the exact sequence is part of the contract.
+
+        A cyclic graph never terminates in the reference; here a full fruitless
+        rotation of the worklist raises instead, which the /compute caller maps to HTTP 400.
+        """
+        done: set = set()
+        emitted: List[Node] = []
+        work = deque(self.nodes)  # right end == reference's list end
+        stalled = 0
+        while work:
+            cand = work.pop()
+            if self._ready(cand, done):
+                done.add(cand)
+                emitted.append(cand)
+                stalled = 0
+            else:
+                work.appendleft(cand)
+                stalled += 1
+                if stalled > len(work):
+                    raise Exception("graph has a cycle")
+        return emitted
+
+    def __str__(self) -> str:
+        lines = ["graph:"]
+        for node in self.nodes:
+            name = node._label()
+            for ch, e in node.outputs.items():
+                tgt = e.output.node._label() if e.output is not None else "*"
+                shape = f" {e.tensor.shape}" if e.tensor is not None else ""
+                lines.append(f"\t{name} --[{ch}]--> {tgt}{shape}")
+            for ch, e in node.inputs.items():
+                if e.input is not None:
+                    continue
+                assert e.tensor is not None
+                lines.append(f"\t* --[{ch}]--> {name} {e.tensor.shape}")
+        return "\n".join(lines)
+
+
+def chain(graph: Graph, names: Iterable[str], channel: str = "o") -> List[Node]:
+    """Convenience used by tests/bench: add nodes and wire them as a linear chain on ``channel``."""
+    nodes = [graph.add_node(n, {}) for n in names]
+    for a, b in zip(nodes, nodes[1:]):
+        graph.connect(a, channel, b, channel)
+    return nodes

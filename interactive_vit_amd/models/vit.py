@@ -1,0 +1,189 @@
+"""ViT model plugin for the node-graph operator API, in the style of the reference's
+``static/models/vgg16.py:10-62``: a ``Model`` subclass that overrides ``list_node_names``,
+``compute``, ``contents`` and ``generate_graph_json``, plus a module-level ``instances()``.
+
+Nodes (``<name>:`` prefix): ``transform``, ``conv_proj``, ``tokens``, ``encoder.layers.<i>``
+(residual-inclusive: the server graph cannot fan out), ``encoder.ln``, ``cls``,
+``heads`` - a linear chain that ends in a client-side ``category`` node - and the standalone
+``forward`` node (whole model in one launch sequence).  Every node takes one input "o" and gives
+one output "o"; images are unbatched ``[3,S,S]`` in the interactive path, a leading batch axis is
+accepted everywhere.
+
+All arithmetic happens in ``libivit.so`` (``interactive_vit_amd.engine.Engine``, hand-written
+gfx950 kernels).  There is no torch/CPU implementation behind these nodes: without the library or a
+GPU, constructing the backend raises and the plugin does not register (the reference logs and skips
+a plugin whose import fails, main/context.py:173-174).
+
+The class is produced by ``make_vit_model_class(ModelBase, PinoutCls)`` so that the same code
+registers against the reference's own ``main.context.Model`` (drop-in) or
+against this package's restatement of it.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from ..vit_config import VARIANTS, VitConfig
+from ..weights import init_weights
+
+
+class VitParameters(torch.nn.Module):
+    """Parameter container with torchvision ``VisionTransformer`` state-dict names.
+
+    It has no ``forward``: the ``Model`` base class only needs an ``nn.Module`` to own the weights
+    (reference main/context.py:39-41); the forward lives on the GPU.
+    """
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor]):
+        super().__init__()
+        for key, value in state_dict.items():
+            *path, leaf = key.split(".")
+            mod = self
+            for part in path:
+                if not hasattr(mod, part):
+                    mod.add_module(part, torch.nn.Module())
+                mod = getattr(mod, part)
+            mod.register_parameter(leaf, torch.nn.Parameter(value.detach().clone(), requires_grad=False))
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("VitParameters holds weights only; the forward runs in libivit.so on the GPU")
+
+
+def node_suffixes(cfg: VitConfig) -> List[str]:
+    return (["transform", "conv_proj", "tokens"] + [f"encoder.layers.{i}" for i in range(cfg.layers)]
+            + ["encoder.ln", "cls", "heads"])
+
+
+def default_categories(classes: int, path: Optional[str] = None) -> List[str]:
+    """Class labels for the ``category`` node: one per line from a local file, else placeholders."""
+    path = path or os.environ.get("IVIT_CATEGORIES")
+    if path and os.path.exists(path):
+        with open(path) as f:
+            cats = [ln.strip() for ln in f if ln.strip()]
+        if len(cats) == classes:
+            return cats
+    return [f"class {i}" for i in range(classes)]
+
+
+def make_vit_model_class(ModelBase, PinoutCls):
+    """Binds the plugin to a concrete operator API (the reference's or this package's)."""
+
+    class VitModel(ModelBase):
+        def __init__(self, cfg: VitConfig, backend, name: Optional[str] = None,
+                     categories: Optional[Sequence[str]] = None):
+            self.cfg = cfg
+            self.backend = backend          # object with run_node(suffix, tensor) -> tensor
+            self.categories = list(categories) if categories is not None else default_categories(cfg.classes)
+            self._suffixes = node_suffixes(cfg)
+            super().__init__(backend.module(), name or cfg.name)
+
+        # -- node set ----------------------------------------------------------------------
+        def chain_node_names(self) -> List[str]:
+            return [self.prefix() + s for s in self._suffixes]
+
+        def list_node_names(self) -> List[str]:
+            return self.chain_node_names() + [self.prefix() + "forward"]
+
+        def generate_graph_json(self) -> Dict:
+            """Chain graph in the client's schema (graph.js:700-758), laid out exactly like
+            ``Model.generate_graph_json`` (context.py:55-73) and closed by a ``category`` node the
+            way vgg16.py:16-29 does."""
+            names = self.chain_node_names()
+            width = int(math.sqrt(len(names)))
+            nodes, edges = [], []
+            for i, name in enumerate(names):
+                nodes.append({"instance": {"kind": "net_node", "endpoint": f"{name}", "params": {}},
+                              "pos": {"x": (i % width) * 200, "y": int(i / width) * 200}})
+                if i:
+                    edges.append({"in_port": {"node": i - 1, "channel": "o"},
+                                  "out_port": {"node": i, "channel": "o"}})
+            i = len(nodes)
+            w = int(math.sqrt(i))
+            nodes.append({"instance": {"kind": "category", "cats": self.categories},
+                          "pos": {"x": (i % w) * 200, "y": int(i / w) * 200}})
+            edges.append({"in_port": {"node": i - 1, "channel": "o"}, "out_port": {"node": i, "channel": "o"}})
+            return {"nodes": nodes, "edges": edges}
+
+        # -- operator interface --------------------------------------------------------------
+        def compute(self, node_name: str, pinin):
+            x = pinin.get("o")
+            assert x is not None
+            suffix = node_name.removeprefix(self.prefix())
+            if suffix != "forward" and suffix not in self._suffixes:
+                raise KeyError(node_name)
+            with torch.no_grad():
+                y = self.backend.run_node(suffix, x)
+            assert isinstance(y, torch.Tensor)
+            out = PinoutCls()
+            out.set("o", y)
+            return out
+
+        def contents(self, node_name: str) -> str:
+            suffix = node_name.removeprefix(self.prefix())
+            c = self.cfg
+            detail = {
+                "transform": "normalise (ImageNet mean/std)",
+                "conv_proj": f"patch embed {c.patch}x{c.patch} &rarr; [{c.patches},{c.dim}]",
+                "tokens": f"[CLS] + position &rarr; [{c.tokens},{c.dim}]",
+                "encoder.ln": "LayerNorm",
+                "cls": f"token 0 &rarr; [{c.dim}]",
+                "heads": f"Linear &rarr; [{c.classes}]",
+                "forward": f"whole model &rarr; [{c.classes}]",
+            }.get(suffix, f"MHSA({c.heads} heads) + MLP({c.mlp})")
+            return f"<p>{node_name}</p> <p>{detail}</p>"
+
+        def io(self, node_name: str) -> Dict:
+            return {"ins": ["o"], "outs": ["o"]}
+
+    return VitModel
+
+
+class HipBackend:
+    """The product backend: owns an ``Engine`` on one GPU.  Raises if the GPU path is unavailable."""
+
+    def __init__(self, cfg: VitConfig, state_dict: Dict[str, torch.Tensor], device: int = 0, max_batch: int = 1):
+        from ..engine import Engine  # raises when libivit.so is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("no MI355X visible (torch.cuda.is_available() is False); the ViT nodes have no CPU path")
+        self.cfg = cfg
+        self._module = VitParameters(state_dict)
+        self.engine = Engine(cfg, state_dict, device=device, max_batch=max_batch)
+
+    def module(self) -> torch.nn.Module:
+        return self._module
+
+    def run_node(self, suffix: str, x: torch.Tensor) -> torch.Tensor:
+        return self.engine.run_node(suffix, x)
+
+
+def build_plugins(ModelBase, PinoutCls, variants: Sequence[str] = ("vit_b_16",), device: int = 0,
+                  max_batch: int = 1, seed: int = 0, state_dicts: Optional[Dict[str, Dict[str, torch.Tensor]]] = None):
+    """What a plugin file's ``instances()`` returns: one registered model per variant.
+
+    Weights: ``state_dicts[name]`` when given (e.g. loaded from a local safetensors file with
+    torchvision key names), else the seeded synthetic initialisation (no network).
+    """
+    cls = make_vit_model_class(ModelBase, PinoutCls)
+    models = []
+    for v in variants:
+        cfg = VARIANTS[v]
+        sd = (state_dicts or {}).get(v) or init_weights(cfg, seed=seed, mode="spec")
+        models.append(cls(cfg, HipBackend(cfg, sd, device=device, max_batch=max_batch)))
+    return models
+
+
+def instances():
+    """Entry point when this file itself is scanned as a plugin (``scan_nodes``)."""
+    try:  # inside the reference tree its own operator API is the base class
+        from main.context import Model as ModelBase
+        from main.graph import Pinout as PinoutCls
+    except ImportError:
+        from ..context import Model as ModelBase
+        from ..graph import Pinout as PinoutCls
+    variants = tuple(v for v in os.environ.get("IVIT_VARIANTS", "vit_b_16").split(",") if v)
+    return build_plugins(ModelBase, PinoutCls, variants,
+                         device=int(os.environ.get("IVIT_DEVICE", "0")),
+                         max_batch=int(os.environ.get("IVIT_MAX_BATCH", "1")))

@@ -1,0 +1,83 @@
+"""Seeded synthetic ViT weights (there is no network for checkpoints).
+
+Key names follow torchvision's ``VisionTransformer`` state-dict so that a local checkpoint in
+that layout can be loaded later without renaming.
+
+``mode="spec"``  - the benchmark initialisation of SURVEY 8(d): matrices and position embedding
+                   ~ N(0, 0.02^2) truncated at 2 sigma, biases and class token 0, LN gains 1.
+``mode="rich"``  - same matrices, but non-trivial biases, LN gains/offsets and class token, so
+                   that parity tests exercise every term of every epilogue.
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import Dict
+
+import torch
+
+from .vit_config import VitConfig
+
+
+def layer_prefix(i: int) -> str:
+    return f"encoder.layers.encoder_layer_{i}."
+
+
+def weight_shapes(cfg: VitConfig) -> Dict[str, tuple]:
+    d, m, p = cfg.dim, cfg.mlp, cfg.patch
+    shapes = {
+        "conv_proj.weight": (d, 3, p, p),
+        "conv_proj.bias": (d,),
+        "class_token": (1, 1, d),
+        "encoder.pos_embedding": (1, cfg.tokens, d),
+    }
+    for i in range(cfg.layers):
+        pre = layer_prefix(i)
+        shapes.update({
+            pre + "ln_1.weight": (d,), pre + "ln_1.bias": (d,),
+            pre + "self_attention.in_proj_weight": (3 * d, d),
+            pre + "self_attention.in_proj_bias": (3 * d,),
+            pre + "self_attention.out_proj.weight": (d, d),
+            pre + "self_attention.out_proj.bias": (d,),
+            pre + "ln_2.weight": (d,), pre + "ln_2.bias": (d,),
+            pre + "mlp.0.weight": (m, d), pre + "mlp.0.bias": (m,),
+            pre + "mlp.3.weight": (d, m), pre + "mlp.3.bias": (d,),
+        })
+    shapes.update({
+        "encoder.ln.weight": (d,), "encoder.ln.bias": (d,),
+        "heads.head.weight": (cfg.classes, d), "heads.head.bias": (cfg.classes,),
+    })
+    return shapes
+
+
+def init_weights(cfg: VitConfig, seed: int = 0, mode: str = "spec") -> Dict[str, torch.Tensor]:
+    assert mode in ("spec", "rich")
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    for name, shape in weight_shapes(cfg).items():
+        is_gain = name.endswith(("ln_1.weight", "ln_2.weight", "ln.weight"))
+        is_matrix = len(shape) >= 2 and name != "class_token"
+        if is_matrix:
+            t = torch.empty(shape, dtype=torch.float32)
+            torch.nn.init.trunc_normal_(t, mean=0.0, std=0.02, a=-0.04, b=0.04, generator=gen)
+        elif mode == "spec":
+            t = torch.ones(shape) if is_gain else torch.zeros(shape)
+        else:
+            r = torch.randn(shape, generator=gen, dtype=torch.float32)
+            t = 1.0 + 0.1 * r if is_gain else 0.05 * r
+        sd[name] = t.contiguous()
+    return sd
+
+
+def state_digest(sd: Dict[str, torch.Tensor]) -> str:
+    """sha256 over names and raw float32 bytes, in key order - pins a seeded state dict."""
+    h = hashlib.sha256()
+    for k in sd:
+        h.update(k.encode())
+        h.update(sd[k].detach().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def synthetic_images(batch: int, cfg: VitConfig, seed: int = 1234, device: str = "cpu") -> torch.Tensor:
+    """x ~ U[0,1) float32 [B,3,S,S] - the browser's image range (img_source_node.js:18-20)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    return torch.rand((batch, 3, cfg.image, cfg.image), generator=gen, dtype=torch.float32, device=device)

@@ -1,0 +1,219 @@
+"""ORACLE - test infrastructure, not product code.
+
+CPU restatement (pure torch, float32 or float64) of the ViT arithmetic the MI355X engine
+implements, node by node.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this file; the product path never does and fails loudly without its HIP library.
+
+What it follows
+---------------
+The reference (0Marble/interactive-vit) contains no ViT: its server math is "whatever leaf
+nn.Module the plugin wraps", called at main/context.py:79-88 (Model.compute -> sub(x)), with
+synthetic nodes handled in the plugin's own compute the way static/models/vgg16.py:37-50 does.
+The arithmetic therefore lives in the third-party dependency torch (reference pins
+pytorch 2.7.0 / torch 2.9.1, requirements.txt:78,89; this container has torch 2.10.0) and the
+ViT contract is SURVEY.md Appendix B / section 8(a2'), torchvision ``VisionTransformer`` semantics:
+
+    P[n,k]   = x[c, gy*p+ky, gx*p+kx]      n = gy*G+gx, k = c*p*p + ky*p + kx     (integer-exact)
+    t[1+n,:] = P[n,:] @ Wp[D,K]^T + bp ;  t[0,:] = cls ;  t += pos[N,D]
+    per layer:  h = LN(t; eps=1e-6); q,k,v = split(h @ Win^T + bin); a = softmax(q k^T/sqrt(dh)) v
+                t = t + a @ Wo^T + bo ;  h = LN(t) ;  t = t + GELU_erf(h @ W1^T + b1) @ W2^T + b2
+    y = LN(t)[0,:] @ Wh^T + bh
+
+PARITY PINNING: the reference has no tests and no golden vectors for this path (main/tests.py:1-3
+is the empty stub), so the *arithmetic* is pinned by (1) an independent cross-check in
+tests/test_oracle.py against torch's own nn.Conv2d / nn.MultiheadAttention / nn.LayerNorm / nn.GELU
+modules (the modules a torchvision ViT is assembled from) and (2) golden activations in
+tests/golden/ produced by driving this oracle through the REFERENCE's real Request.decode ->
+Context.compute -> Response.encode (tests/golden/make_golden.py).  The node plumbing around it
+(ordering, wire bytes, Model node naming) is pinned by fixtures generated from the reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+
+
+def layer_prefix(i: int) -> str:
+    return f"encoder.layers.encoder_layer_{i}."
+
+
+# ----------------------------------------------------------------------------------------------
+# integer bookkeeping (bit-exact class)
+# ----------------------------------------------------------------------------------------------
+def unfold_index(image: int, patch: int) -> np.ndarray:
+    """int64 [Np, K]: flat offset into a [3,S,S] image of patch n, unfold column k.
+
+    Pure-Python loops on purpose (small, obviously right): n = gy*G+gx, k = c*p*p + ky*p + kx.
+    """
+    g = image // patch
+    k_len = 3 * patch * patch
+    idx = np.empty((g * g, k_len), dtype=np.int64)
+    for gy in range(g):
+        for gx in range(g):
+            n = gy * g + gx
+            for c in range(3):
+                for ky in range(patch):
+                    for kx in range(patch):
+                        k = c * patch * patch + ky * patch + kx
+                        idx[n, k] = c * image * image + (gy * patch + ky) * image + (gx * patch + kx)
+    return idx
+
+
+def unfold(x: torch.Tensor, image: int, patch: int) -> torch.Tensor:
+    """[B,3,S,S] -> [B,Np,K] by gathering through ``unfold_index`` (no arithmetic on values)."""
+    idx = torch.from_numpy(unfold_index(image, patch)).reshape(-1)
+    b = x.shape[0]
+    flat = x.reshape(b, -1)
+    g = image // patch
+    return flat[:, idx].reshape(b, g * g, 3 * patch * patch)
+
+
+def token_row(batch_index: int, token: int, tokens: int) -> int:
+    """Row of (image b, token t) in the engine's [B*N, D] activation matrices."""
+    return batch_index * tokens + token
+
+
+# ----------------------------------------------------------------------------------------------
+# floating-point nodes
+# ----------------------------------------------------------------------------------------------
+def _w(sd: Dict[str, torch.Tensor], key: str, dtype) -> torch.Tensor:
+    return sd[key].to(dtype)
+
+
+def transform(x: torch.Tensor) -> torch.Tensor:
+    """Per-channel (x - mean) / std; x is [B,3,S,S] in [0,1]."""
+    mean = torch.tensor(MEAN, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(STD, dtype=x.dtype).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+def conv_proj(x: torch.Tensor, sd, cfg) -> torch.Tensor:
+    """Patch embedding as unfold + GEMM: [B,3,S,S] -> [B,Np,D]."""
+    dt = x.dtype
+    p = unfold(x, cfg.image, cfg.patch)
+    w = _w(sd, "conv_proj.weight", dt).reshape(cfg.dim, -1)
+    return p @ w.t() + _w(sd, "conv_proj.bias", dt)
+
+
+def tokens(t: torch.Tensor, sd, cfg) -> torch.Tensor:
+    """Prepend the class token, add the learned position embedding: [B,Np,D] -> [B,N,D]."""
+    dt = t.dtype
+    cls = _w(sd, "class_token", dt).expand(t.shape[0], -1, -1)
+    return torch.cat([cls, t], dim=1) + _w(sd, "encoder.pos_embedding", dt)
+
+
+def layer_norm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+def gelu_erf(x: torch.Tensor) -> torch.Tensor:
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False):
+    dt = h.dtype
+    pre = layer_prefix(i) + "self_attention."
+    b, n, d = h.shape
+    hd = cfg.head_dim
+    qkv = h @ _w(sd, pre + "in_proj_weight", dt).t() + _w(sd, pre + "in_proj_bias", dt)
+    q, k, v = qkv.split(d, dim=-1)
+
+    def heads(t):
+        return t.reshape(b, n, cfg.heads, hd).transpose(1, 2)  # [B,H,N,dh]
+
+    q, k, v = heads(q), heads(k), heads(v)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    p = torch.softmax(s, dim=-1)
+    a = (p @ v).transpose(1, 2).reshape(b, n, d)
+    out = a @ _w(sd, pre + "out_proj.weight", dt).t() + _w(sd, pre + "out_proj.bias", dt)
+    return (out, p) if return_probs else out
+
+
+def encoder_layer(x: torch.Tensor, sd, i: int, cfg) -> torch.Tensor:
+    """Residual-inclusive block i: [B,N,D] -> [B,N,D]."""
+    dt = x.dtype
+    pre = layer_prefix(i)
+    h = layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps)
+    x = x + attention(h, sd, i, cfg)
+    h = layer_norm(x, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps)
+    m = gelu_erf(h @ _w(sd, pre + "mlp.0.weight", dt).t() + _w(sd, pre + "mlp.0.bias", dt))
+    return x + m @ _w(sd, pre + "mlp.3.weight", dt).t() + _w(sd, pre + "mlp.3.bias", dt)
+
+
+def encoder_ln(x: torch.Tensor, sd, cfg) -> torch.Tensor:
+    dt = x.dtype
+    return layer_norm(x, _w(sd, "encoder.ln.weight", dt), _w(sd, "encoder.ln.bias", dt), cfg.ln_eps)
+
+
+def cls(x: torch.Tensor) -> torch.Tensor:
+    return x[:, 0, :]
+
+
+def heads(x: torch.Tensor, sd) -> torch.Tensor:
+    dt = x.dtype
+    return x @ _w(sd, "heads.head.weight", dt).t() + _w(sd, "heads.head.bias", dt)
+
+
+def node_suffixes(cfg) -> List[str]:
+    """The chain of nodes of the plugin, in graph order (SURVEY 8(a2'))."""
+    return (["transform", "conv_proj", "tokens"]
+            + [f"encoder.layers.{i}" for i in range(cfg.layers)]
+            + ["encoder.ln", "cls", "heads"])
+
+
+def run_node(suffix: str, x: torch.Tensor, sd, cfg) -> torch.Tensor:
+    """One node on a BATCHED input (leading B axis)."""
+    if suffix == "transform":
+        return transform(x)
+    if suffix == "conv_proj":
+        return conv_proj(x, sd, cfg)
+    if suffix == "tokens":
+        return tokens(x, sd, cfg)
+    if suffix.startswith("encoder.layers."):
+        return encoder_layer(x, sd, int(suffix.rsplit(".", 1)[1]), cfg)
+    if suffix == "encoder.ln":
+        return encoder_ln(x, sd, cfg)
+    if suffix == "cls":
+        return cls(x)
+    if suffix == "heads":
+        return heads(x, sd)
+    if suffix == "forward":
+        return forward(x, sd, cfg)["logits"]
+    raise KeyError(suffix)
+
+
+def forward(x: torch.Tensor, sd, cfg, keep: bool = False) -> Dict[str, torch.Tensor]:
+    """Whole model, [B,3,S,S] in [0,1] -> {"logits": [B,classes], "cls": [B,D], + every node}."""
+    acts: Dict[str, torch.Tensor] = {}
+    t = x
+    for s in node_suffixes(cfg):
+        t = run_node(s, t, sd, cfg)
+        if keep or s in ("cls", "heads"):
+            acts[s] = t
+    acts["logits"] = acts["heads"]
+    return acts
+
+
+# unbatched ranks of each node's input, to accept both [3,S,S] and [B,3,S,S] style tensors
+INPUT_RANK = {"transform": 3, "conv_proj": 3, "tokens": 2, "encoder.ln": 2, "cls": 2, "heads": 1,
+              "forward": 3}
+
+
+def input_rank(suffix: str) -> int:
+    return 2 if suffix.startswith("encoder.layers.") else INPUT_RANK[suffix]
+
+
+def run_node_any(suffix: str, x: torch.Tensor, sd, cfg) -> torch.Tensor:
+    """Accepts the unbatched interactive form ([3,S,S], [N,D], [D]) or the batched one."""
+    if x.dim() == input_rank(suffix):
+        return run_node(suffix, x.unsqueeze(0), sd, cfg).squeeze(0)
+    return run_node(suffix, x, sd, cfg)

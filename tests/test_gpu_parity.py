@@ -1,0 +1,179 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bars (BASELINE.json north_star / SURVEY 8(d)):
+
+* patch index / unfold bookkeeping: BIT-EXACT;
+* floating point nodes: max|gpu - ref| / max|ref| <= 1e-3 per node on identical inputs (bf16 MFMA
+  operands, f32 accumulation / statistics / residual stream), and for the whole forward.
+"""
+import numpy as np
+import pytest
+import torch
+
+from interactive_vit_amd.vit_config import VARIANTS, test_config
+from interactive_vit_amd.weights import init_weights, synthetic_images
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-3   # the tolerance north_star states for bf16
+
+
+def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def small():
+    from interactive_vit_amd.engine import Engine
+    cfg = test_config()
+    sd = init_weights(cfg, seed=3, mode="rich")
+    eng = Engine(cfg, sd, device=0, max_batch=5)
+    yield cfg, sd, eng
+    eng.close()
+
+
+def test_library_is_the_hip_build(built_lib):
+    from interactive_vit_amd import engine
+    lib = engine.load_library()
+    assert lib.ivit_abi_version() == 1
+    assert b"gfx950" in lib.ivit_build_info()
+
+
+def test_unfold_bit_exact(small):
+    from oracle import vit_oracle
+    cfg, sd, eng = small
+    x = synthetic_images(3, cfg, seed=11).cuda()
+    # no transform: pure gather + bf16 rounding
+    got = eng.debug_unfold(x, normalise=False).cpu()
+    ref = vit_oracle.unfold(x.cpu(), cfg.image, cfg.patch).reshape(-1, cfg.patch_k).to(torch.bfloat16).float()
+    assert torch.equal(got, ref)
+    # fused transform + unfold: (x-mean)/std in f32, then the same rounding
+    got = eng.debug_unfold(x, normalise=True).cpu()
+    ref = vit_oracle.unfold(vit_oracle.transform(x.cpu()), cfg.image, cfg.patch).reshape(-1, cfg.patch_k)
+    assert torch.equal(got, ref.to(torch.bfloat16).float())
+
+
+def test_unfold_index_identity_image(small):
+    """Every pixel carries its own flat offset (exactly representable: offsets < 2^24 in f32 and
+    the test image is small enough for bf16 only through the index map) -> compare index maps."""
+    from oracle import vit_oracle
+    from interactive_vit_amd.engine import unfold_offset
+    cfg, _, _ = small
+    idx = vit_oracle.unfold_index(cfg.image, cfg.patch)
+    for n in (0, 1, cfg.grid, cfg.patches - 1):
+        for k in (0, 1, cfg.patch, cfg.patch * cfg.patch, cfg.patch_k - 1):
+            assert unfold_offset(cfg.image, cfg.patch, n, k) == idx[n, k]
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_every_node_matches_oracle(small, batch):
+    """Each node alone, fed the ORACLE's input for that node (errors do not accumulate)."""
+    from oracle import vit_oracle
+    cfg, sd, eng = small
+    x = synthetic_images(batch, cfg, seed=5)
+    acts = vit_oracle.forward(x, sd, cfg, keep=True)
+    cur = x
+    for suffix in vit_oracle.node_suffixes(cfg):
+        ref = acts[suffix]
+        got = eng.run_node(suffix, cur.cuda()).cpu()
+        assert got.shape == ref.shape, suffix
+        err = rel_err(got, ref)
+        assert err <= REL_TOL, f"{suffix}: rel err {err:.3e}"
+        cur = ref
+
+
+def test_unbatched_interactive_shapes(small):
+    from oracle import vit_oracle
+    cfg, sd, eng = small
+    x = synthetic_images(1, cfg, seed=6)[0]            # [3,S,S] as the browser sends it
+    cur = x
+    for suffix in vit_oracle.node_suffixes(cfg):
+        ref = vit_oracle.run_node_any(suffix, cur, sd, cfg)
+        got = eng.run_node(suffix, cur)                # CPU tensor in -> host path -> CPU tensor out
+        assert got.device.type == "cpu" and got.dtype == torch.float32
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) <= REL_TOL, suffix
+        cur = ref
+
+
+def test_fused_forward_matches_chain_and_oracle(small):
+    from oracle import vit_oracle
+    cfg, sd, eng = small
+    x = synthetic_images(5, cfg, seed=7)
+    ref = vit_oracle.forward(x, sd, cfg)
+    logits, cls = eng.forward(x.cuda(), 0, len(eng.stages), want_cls=True)
+    assert rel_err(logits, ref["logits"]) <= REL_TOL
+    # class-token features after encoder.ln feed `heads`; cls_out is the [B,D] f32 row of it
+    ln = vit_oracle.encoder_ln(vit_oracle.forward(x, sd, cfg, keep=True)[f"encoder.layers.{cfg.layers - 1}"], sd, cfg)
+    assert rel_err(cls, ln[:, 0]) <= REL_TOL
+    # node-by-node on the GPU gives the SAME bits as the fused range (same kernels, same order)
+    cur = x.cuda()
+    for suffix in vit_oracle.node_suffixes(cfg):
+        cur = eng.run_node(suffix, cur)
+    assert torch.equal(cur.cpu(), logits.cpu())
+
+
+def test_stage_ranges_compose(small):
+    cfg, sd, eng = small
+    x = synthetic_images(2, cfg, seed=8).cuda()
+    full = eng.forward(x, 0, len(eng.stages))
+    ns = len(eng.stages)
+    for cut in (1, 2, 3, 4, ns - 3, ns - 2, ns - 1):
+        a = eng.forward(x, 0, cut)
+        b = eng.forward(a, cut, ns)
+        assert torch.equal(b, full), f"cut at {cut}"
+
+
+def test_errors_are_exceptions_with_messages(small):
+    from interactive_vit_amd.engine import EngineError
+    cfg, sd, eng = small
+    with pytest.raises(EngineError, match="expects input"):
+        eng.run_node("tokens", torch.zeros(3, 3))
+    with pytest.raises(EngineError, match="batch"):
+        eng.forward(torch.zeros(6, 3, cfg.image, cfg.image), 0, 1)     # > max_batch
+    with pytest.raises(EngineError, match="stage range"):
+        eng.forward(torch.zeros(3, cfg.image, cfg.image), 2, 2)
+
+
+def test_vit_tiny_forward():
+    """BASELINE config 1 model (ViT-Ti/16, 197 tokens) on one image and a ragged batch."""
+    from interactive_vit_amd.engine import Engine
+    from oracle import vit_oracle
+    cfg = VARIANTS["vit_ti_16"]
+    sd = init_weights(cfg, seed=0, mode="rich")
+    eng = Engine(cfg, sd, device=0, max_batch=3)
+    try:
+        x = synthetic_images(3, cfg, seed=1234)
+        acts = vit_oracle.forward(x, sd, cfg, keep=True)
+        logits = eng.forward(x.cuda(), 0, len(eng.stages)).cpu()
+        assert rel_err(logits, acts["logits"]) <= REL_TOL
+        mid = eng.forward(x.cuda(), 0, 3 + 6).cpu()          # after encoder layer 5
+        assert rel_err(mid, acts["encoder.layers.5"]) <= REL_TOL
+    finally:
+        eng.close()
+
+
+def test_vit_b16_batch_parity_and_properties():
+    """BASELINE config 2 sizes (ViT-B/16): oracle on a 2-image sample (seconds of CPU), plus
+    size-independent properties at the full batch of 64: batch independence (image i alone ==
+    image i inside the batch, bit for bit) and determinism."""
+    from interactive_vit_amd.engine import Engine
+    from oracle import vit_oracle
+    cfg = VARIANTS["vit_b_16"]
+    sd = init_weights(cfg, seed=0, mode="spec")
+    eng = Engine(cfg, sd, device=0, max_batch=64)
+    try:
+        x = synthetic_images(64, cfg, seed=1234)
+        xg = x.cuda()
+        logits = eng.forward(xg, 0, len(eng.stages))
+        again = eng.forward(xg, 0, len(eng.stages))
+        assert torch.equal(logits, again)
+        ref = vit_oracle.forward(x[:2], sd, cfg)["logits"]
+        assert rel_err(logits[:2], ref) <= REL_TOL
+        for i in (0, 17, 63):
+            alone = eng.forward(xg[i:i + 1].contiguous(), 0, len(eng.stages))
+            assert torch.equal(alone[0], logits[i]), f"image {i} depends on its batch"
+        assert torch.isfinite(logits).all()
+    finally:
+        eng.close()
