@@ -149,6 +149,10 @@ class Response:
             if nbytes:
                 view[pos:pos + nbytes] = memoryview(a.reshape(-1)).cast("B")
             pos += nbytes
+        if not arrays:
+            # reference quirk (ref :108-109): the pad is a seek past the end that nothing follows, so
+            # with zero blocks the pad bytes are never materialised although byte_size counts them
+            return bytes(out[:_HEADER.size + len(json_utf8)])
         return bytes(out)
 
 

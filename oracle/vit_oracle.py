@@ -19,6 +19,17 @@ ViT contract is SURVEY.md Appendix B / section 8(a2'), torchvision ``VisionTrans
                 t = t + a @ Wo^T + bo ;  h = LN(t) ;  t = t + GELU_erf(h @ W1^T + b1) @ W2^T + b2
     y = LN(t)[0,:] @ Wh^T + bh
 
+TWO MODES.  ``emulate=False`` is the plain float32 (or float64) forward - "the reference CPU
+node-graph forward".  ``emulate=True`` evaluates the SAME formulas but rounds to bfloat16 at exactly
+the points where the engine's data path is bf16 (GEMM operands = LN output / unfold image /
+attention output / GELU output, weight matrices, the stored q|k|v, the softmax numerators P fed to
+P.V); accumulation, LN/softmax statistics, biases and the residual stream stay float32/64 as in the
+engine.  bf16 operand rounding alone is a ~1.6e-3 rms relative perturbation of every random-sign
+dot product (two operands x 2^-9/sqrt(3)), i.e. ABOVE north_star's 1e-3: against the plain-f32
+forward a bf16-MFMA engine cannot be inside 1e-3, against the rounding-aware forward it must be
+(only accumulation order differs) - so kernel parity is gated on ``emulate=True`` and the distance
+to the plain forward is measured and reported beside it (tests/test_gpu_parity.py).
+
 PARITY PINNING: the reference has no tests and no golden vectors for this path (main/tests.py:1-3
 is the empty stub), so the *arithmetic* is pinned by (1) an independent cross-check in
 tests/test_oracle.py against torch's own nn.Conv2d / nn.MultiheadAttention / nn.LayerNorm / nn.GELU
@@ -83,8 +94,17 @@ def token_row(batch_index: int, token: int, tokens: int) -> int:
 # ----------------------------------------------------------------------------------------------
 # floating-point nodes
 # ----------------------------------------------------------------------------------------------
-def _w(sd: Dict[str, torch.Tensor], key: str, dtype) -> torch.Tensor:
-    return sd[key].to(dtype)
+def rnd(t: torch.Tensor, emulate: bool) -> torch.Tensor:
+    """bf16 round-to-nearest-even of an activation at an engine rounding point (emulate mode)."""
+    return t.to(torch.bfloat16).to(t.dtype) if emulate else t
+
+
+def _w(sd: Dict[str, torch.Tensor], key: str, dtype, emulate: bool = False) -> torch.Tensor:
+    """A parameter in the compute dtype; ``emulate`` rounds it to bf16 first (weight MATRICES only)."""
+    w = sd[key]
+    if emulate:
+        w = w.to(torch.float32).to(torch.bfloat16)
+    return w.to(dtype)
 
 
 def transform(x: torch.Tensor) -> torch.Tensor:
@@ -94,11 +114,11 @@ def transform(x: torch.Tensor) -> torch.Tensor:
     return (x - mean) / std
 
 
-def conv_proj(x: torch.Tensor, sd, cfg) -> torch.Tensor:
+def conv_proj(x: torch.Tensor, sd, cfg, emulate: bool = False) -> torch.Tensor:
     """Patch embedding as unfold + GEMM: [B,3,S,S] -> [B,Np,D]."""
     dt = x.dtype
-    p = unfold(x, cfg.image, cfg.patch)
-    w = _w(sd, "conv_proj.weight", dt).reshape(cfg.dim, -1)
+    p = rnd(unfold(x, cfg.image, cfg.patch), emulate)
+    w = _w(sd, "conv_proj.weight", dt, emulate).reshape(cfg.dim, -1)
     return p @ w.t() + _w(sd, "conv_proj.bias", dt)
 
 
@@ -119,12 +139,12 @@ def gelu_erf(x: torch.Tensor) -> torch.Tensor:
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False):
+def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False, emulate: bool = False):
     dt = h.dtype
     pre = layer_prefix(i) + "self_attention."
     b, n, d = h.shape
     hd = cfg.head_dim
-    qkv = h @ _w(sd, pre + "in_proj_weight", dt).t() + _w(sd, pre + "in_proj_bias", dt)
+    qkv = rnd(h @ _w(sd, pre + "in_proj_weight", dt, emulate).t() + _w(sd, pre + "in_proj_bias", dt), emulate)
     q, k, v = qkv.split(d, dim=-1)
 
     def heads(t):
@@ -132,21 +152,28 @@ def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False):
 
     q, k, v = heads(q), heads(k), heads(v)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
-    p = torch.softmax(s, dim=-1)
-    a = (p @ v).transpose(1, 2).reshape(b, n, d)
-    out = a @ _w(sd, pre + "out_proj.weight", dt).t() + _w(sd, pre + "out_proj.bias", dt)
+    if emulate:
+        # engine: numerators e = exp(s - max) in f32, row sum of the UNROUNDED e, P.V on bf16(e)
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        p = e / e.sum(dim=-1, keepdim=True)
+        a = (rnd(e, True) @ v) / e.sum(dim=-1, keepdim=True)
+    else:
+        p = torch.softmax(s, dim=-1)
+        a = p @ v
+    a = rnd(a.transpose(1, 2).reshape(b, n, d), emulate)
+    out = a @ _w(sd, pre + "out_proj.weight", dt, emulate).t() + _w(sd, pre + "out_proj.bias", dt)
     return (out, p) if return_probs else out
 
 
-def encoder_layer(x: torch.Tensor, sd, i: int, cfg) -> torch.Tensor:
+def encoder_layer(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> torch.Tensor:
     """Residual-inclusive block i: [B,N,D] -> [B,N,D]."""
     dt = x.dtype
     pre = layer_prefix(i)
-    h = layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps)
-    x = x + attention(h, sd, i, cfg)
-    h = layer_norm(x, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps)
-    m = gelu_erf(h @ _w(sd, pre + "mlp.0.weight", dt).t() + _w(sd, pre + "mlp.0.bias", dt))
-    return x + m @ _w(sd, pre + "mlp.3.weight", dt).t() + _w(sd, pre + "mlp.3.bias", dt)
+    h = rnd(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), emulate)
+    x = x + attention(h, sd, i, cfg, emulate=emulate)
+    h = rnd(layer_norm(x, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps), emulate)
+    m = rnd(gelu_erf(h @ _w(sd, pre + "mlp.0.weight", dt, emulate).t() + _w(sd, pre + "mlp.0.bias", dt)), emulate)
+    return x + m @ _w(sd, pre + "mlp.3.weight", dt, emulate).t() + _w(sd, pre + "mlp.3.bias", dt)
 
 
 def encoder_ln(x: torch.Tensor, sd, cfg) -> torch.Tensor:
@@ -158,9 +185,9 @@ def cls(x: torch.Tensor) -> torch.Tensor:
     return x[:, 0, :]
 
 
-def heads(x: torch.Tensor, sd) -> torch.Tensor:
+def heads(x: torch.Tensor, sd, emulate: bool = False) -> torch.Tensor:
     dt = x.dtype
-    return x @ _w(sd, "heads.head.weight", dt).t() + _w(sd, "heads.head.bias", dt)
+    return rnd(x, emulate) @ _w(sd, "heads.head.weight", dt, emulate).t() + _w(sd, "heads.head.bias", dt)
 
 
 def node_suffixes(cfg) -> List[str]:
@@ -170,33 +197,41 @@ def node_suffixes(cfg) -> List[str]:
             + ["encoder.ln", "cls", "heads"])
 
 
-def run_node(suffix: str, x: torch.Tensor, sd, cfg) -> torch.Tensor:
+def run_node(suffix: str, x: torch.Tensor, sd, cfg, emulate: bool = False) -> torch.Tensor:
     """One node on a BATCHED input (leading B axis)."""
     if suffix == "transform":
         return transform(x)
     if suffix == "conv_proj":
-        return conv_proj(x, sd, cfg)
+        return conv_proj(x, sd, cfg, emulate)
     if suffix == "tokens":
         return tokens(x, sd, cfg)
     if suffix.startswith("encoder.layers."):
-        return encoder_layer(x, sd, int(suffix.rsplit(".", 1)[1]), cfg)
+        return encoder_layer(x, sd, int(suffix.rsplit(".", 1)[1]), cfg, emulate)
     if suffix == "encoder.ln":
         return encoder_ln(x, sd, cfg)
     if suffix == "cls":
         return cls(x)
     if suffix == "heads":
-        return heads(x, sd)
+        return heads(x, sd, emulate)
     if suffix == "forward":
-        return forward(x, sd, cfg)["logits"]
+        return forward(x, sd, cfg, emulate=emulate)["logits"]
     raise KeyError(suffix)
 
 
-def forward(x: torch.Tensor, sd, cfg, keep: bool = False) -> Dict[str, torch.Tensor]:
-    """Whole model, [B,3,S,S] in [0,1] -> {"logits": [B,classes], "cls": [B,D], + every node}."""
+def forward(x: torch.Tensor, sd, cfg, keep: bool = False, emulate: bool = False) -> Dict[str, torch.Tensor]:
+    """Whole model, [B,3,S,S] in [0,1] -> {"logits": [B,classes], "cls": [B,D], + every node}.
+
+    In emulate mode the transform is evaluated in float32 exactly as the engine does (its result is
+    then rounded to bf16 by conv_proj), whatever the dtype of the rest."""
     acts: Dict[str, torch.Tensor] = {}
     t = x
     for s in node_suffixes(cfg):
-        t = run_node(s, t, sd, cfg)
+        if emulate and s == "transform":
+            t = transform(t.to(torch.float32)).to(x.dtype)
+            if keep:
+                acts[s] = t
+            continue
+        t = run_node(s, t, sd, cfg, emulate)
         if keep or s in ("cls", "heads"):
             acts[s] = t
     acts["logits"] = acts["heads"]
@@ -212,8 +247,8 @@ def input_rank(suffix: str) -> int:
     return 2 if suffix.startswith("encoder.layers.") else INPUT_RANK[suffix]
 
 
-def run_node_any(suffix: str, x: torch.Tensor, sd, cfg) -> torch.Tensor:
+def run_node_any(suffix: str, x: torch.Tensor, sd, cfg, emulate: bool = False) -> torch.Tensor:
     """Accepts the unbatched interactive form ([3,S,S], [N,D], [D]) or the batched one."""
     if x.dim() == input_rank(suffix):
-        return run_node(suffix, x.unsqueeze(0), sd, cfg).squeeze(0)
-    return run_node(suffix, x, sd, cfg)
+        return run_node(suffix, x.unsqueeze(0), sd, cfg, emulate).squeeze(0)
+    return run_node(suffix, x, sd, cfg, emulate)

@@ -1,0 +1,110 @@
+"""The C-ABI shared library (no GPU needed): builds for gfx950, loads, exports every symbol that
+include/ivit.h declares, answers the host-side bookkeeping entry points, and FAILS LOUDLY where a
+GPU would be needed - there is no CPU fallback behind the ViT operators."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from interactive_vit_amd import engine
+from interactive_vit_amd.vit_config import VARIANTS
+from interactive_vit_amd.vit_config import test_config as small_config
+from interactive_vit_amd.weights import init_weights
+from oracle import vit_oracle as vo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NO_GPU = not torch.cuda.is_available()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "ivit.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ivit_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == sorted(engine.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (ivit_[a-z_0-9]+)", out))
+    assert set(header_symbols()) <= exported
+    lib = engine.load_library()
+    assert lib.ivit_abi_version() == 1
+    assert b"gfx950" in lib.ivit_build_info()
+
+
+def test_library_contains_gfx950_code_objects(built_lib):
+    data = open(built_lib, "rb").read()
+    assert b"gfx950" in data
+    for kernel in (b"ivit_gemm_bf16_128x128x64", b"ivit_attention_bf16", b"ivit_layernorm", b"ivit_unfold"):
+        assert kernel in data, kernel
+
+
+def test_stage_table(built_lib):
+    for cfg in (small_config(), VARIANTS["vit_b_16"], VARIANTS["vit_l_16_384"], VARIANTS["vit_h_14"]):
+        names = engine.stage_names(cfg)
+        assert len(names) == 6 + cfg.layers == len(vo.node_suffixes(cfg))
+        assert names == vo.node_suffixes(cfg)
+        s, n, d = cfg.image, cfg.tokens, cfg.dim
+        assert engine.stage_shape(cfg, 0, 0) == (3, s, s) == engine.stage_shape(cfg, 0, 1)
+        assert engine.stage_shape(cfg, 1, 1) == (cfg.patches, d)
+        assert engine.stage_shape(cfg, 2, 1) == (n, d)
+        assert engine.stage_shape(cfg, 3 + cfg.layers, 1) == (n, d)
+        assert engine.stage_shape(cfg, 4 + cfg.layers, 1) == (d,)
+        assert engine.stage_shape(cfg, 5 + cfg.layers, 1) == (cfg.classes,)
+        for i in range(len(names) - 1):   # the chain is well formed: out(i) == in(i+1)
+            assert engine.stage_shape(cfg, i, 1) == engine.stage_shape(cfg, i + 1, 0)
+        with pytest.raises(engine.EngineError):
+            engine.stage_shape(cfg, len(names), 0)
+
+
+@pytest.mark.parametrize("image,patch", [(64, 16), (224, 16), (224, 14), (384, 16)])
+def test_unfold_offset_bit_exact(built_lib, image, patch):
+    """The engine's unfold bookkeeping function (the one its device kernel is compiled from)
+    against the oracle's loop-built index map - every (n, k) for small cases, a dense sample else."""
+    idx = vo.unfold_index(image, patch)
+    lib = engine.load_library()
+    rng = np.random.default_rng(0)
+    n_all, k_all = idx.shape
+    if n_all * k_all <= 20000:
+        pairs = [(n, k) for n in range(n_all) for k in range(k_all)]
+    else:
+        pairs = list(zip(rng.integers(0, n_all, 20000).tolist(), rng.integers(0, k_all, 20000).tolist()))
+        pairs += [(0, 0), (n_all - 1, k_all - 1), (n_all - 1, 0), (0, k_all - 1)]
+    for n, k in pairs:
+        assert lib.ivit_unfold_offset(image, patch, n, k) == idx[n, k]
+
+
+def test_bad_configs_are_rejected_with_messages(built_lib):
+    lib = engine.load_library()
+    h = ctypes.c_void_p()
+    for field, value, text in (("image", 230, "multiple of patch"), ("dim", 100, "multiple of 64"),
+                               ("heads", 5, "divisible by heads"), ("max_batch", 0, "max_batch")):
+        cfg = small_config()
+        c = engine._config_c(cfg, 0, 1)
+        setattr(c, field, value)
+        assert lib.ivit_create(ctypes.byref(c), ctypes.byref(h)) != 0
+        assert text in lib.ivit_last_error().decode()
+    assert lib.ivit_create(None, ctypes.byref(h)) != 0
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-GPU failure mode")
+def test_no_gpu_means_no_engine(built_lib):
+    cfg = small_config()
+    sd = init_weights(cfg, 0)
+    with pytest.raises(engine.EngineError):
+        engine.Engine(cfg, sd)
+    from interactive_vit_amd.models.vit import HipBackend
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        HipBackend(cfg, sd)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.load_library(str(tmp_path / "libivit.so"))

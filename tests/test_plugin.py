@@ -1,0 +1,103 @@
+"""The ViT model plugin as seen through the operator API (CPU: oracle backend injected - the
+product backend needs the GPU and is covered by tests/test_gpu_*.py)."""
+import json
+import os
+
+import pytest
+import torch
+
+from interactive_vit_amd import context as ctxmod
+from interactive_vit_amd.context import Context, Model
+from interactive_vit_amd.graph import Graph, Pinout
+from interactive_vit_amd.models.vit import VitParameters, default_categories, make_vit_model_class, node_suffixes
+from interactive_vit_amd.vit_config import VARIANTS
+from interactive_vit_amd.vit_config import test_config as small_config
+from interactive_vit_amd.weights import init_weights, synthetic_images, weight_shapes
+from oracle import vit_oracle as vo
+from oracle.cpu_backend import OracleBackend
+
+
+@pytest.fixture()
+def plugin(tmp_path):
+    (tmp_path / "static" / "graphs").mkdir(parents=True)
+    ctxmod.set_base_dir(str(tmp_path))
+    cfg = small_config()
+    sd = init_weights(cfg, seed=3, mode="rich")
+    vit = make_vit_model_class(Model, Pinout)(cfg, OracleBackend(cfg, sd))
+    ctx = Context()
+    vit.register(ctx)
+    return cfg, sd, vit, ctx, tmp_path
+
+
+def test_registration_and_graph_file(plugin):
+    cfg, sd, vit, ctx, base = plugin
+    names = vit.list_node_names()
+    assert names == [f"{cfg.name}:{s}" for s in node_suffixes(cfg)] + [f"{cfg.name}:forward"]
+    assert sorted(ctx.nodes) == sorted(names)
+    assert all("/" not in n for n in names)             # node names are URL path segments (urls.py:12-13)
+    gj = json.load(open(base / "static" / "graphs" / f"{cfg.name}.json"))
+    chain = vit.chain_node_names()
+    assert [n["instance"].get("endpoint") for n in gj["nodes"][:-1]] == chain
+    assert gj["nodes"][-1]["instance"]["kind"] == "category"
+    assert len(gj["nodes"][-1]["instance"]["cats"]) == cfg.classes
+    assert len(gj["edges"]) == len(chain)               # chain edges + the edge into `category`
+    assert gj["edges"][-1] == {"in_port": {"node": len(chain) - 1, "channel": "o"}, "out_port": {"node": len(chain), "channel": "o"}}
+    for n in names:
+        assert ctx.get_node(n).io({}) == {"ins": ["o"], "outs": ["o"]}
+        assert ctx.get_node(n).contents({}).startswith(f"<p>{n}</p>")
+
+
+def test_chain_through_context_matches_direct_forward(plugin):
+    cfg, sd, vit, ctx, _ = plugin
+    img = synthetic_images(1, cfg, seed=9)[0]
+    g = Graph()
+    nodes = [g.add_node(n, {}) for n in vit.chain_node_names()]
+    for a, b in zip(nodes, nodes[1:]):
+        g.connect(a, "o", b, "o")
+    g.add_input(img, nodes[0], "o")
+    ctx.compute(g)
+    logits = nodes[-1].get_pinout().get("o")
+    assert logits.shape == (cfg.classes,)                # what the client `category` node expects
+    ref = vo.forward(img.unsqueeze(0), sd, cfg)["logits"][0]
+    assert torch.allclose(logits, ref, atol=1e-5)
+    fwd = ctx.get_node(f"{cfg.name}:forward").compute({}, Pinout({"o": img})).get("o")
+    assert torch.allclose(fwd, ref, atol=1e-5)
+    # shapes the browser viewers rely on
+    assert nodes[0].get_pinout().get("o").shape == (3, cfg.image, cfg.image)
+    assert nodes[2].get_pinout().get("o").shape == (cfg.tokens, cfg.dim)
+
+
+def test_missing_input_and_unknown_node(plugin):
+    cfg, sd, vit, ctx, _ = plugin
+    with pytest.raises(AssertionError):
+        ctx.get_node(f"{cfg.name}:tokens").compute({}, Pinout())
+    with pytest.raises(KeyError):
+        ctx.get_node(f"{cfg.name}:encoder.layers.99")
+    with pytest.raises(KeyError):
+        vit.compute(f"{cfg.name}:nope", Pinout({"o": torch.zeros(1)}))
+
+
+def test_parameter_container_has_torchvision_names():
+    cfg = small_config()
+    sd = init_weights(cfg, seed=0)
+    mod = VitParameters(sd)
+    assert sorted(mod.state_dict().keys()) == sorted(sd.keys()) == sorted(weight_shapes(cfg).keys())
+    for k, v in mod.state_dict().items():
+        assert torch.equal(v, sd[k])
+    with pytest.raises(RuntimeError):
+        mod(torch.zeros(1))
+
+
+def test_categories_from_file(tmp_path):
+    p = tmp_path / "cats.txt"
+    p.write_text("\n".join(f"label {i}" for i in range(7)))
+    assert default_categories(7, str(p))[3] == "label 3"
+    assert default_categories(5, str(p)) == [f"class {i}" for i in range(5)]   # wrong length -> placeholders
+
+
+def test_variant_table_matches_survey():
+    assert VARIANTS["vit_b_16"].macs_per_image() == 17563828224
+    assert round(VARIANTS["vit_ti_16"].macs_per_image() / 1e9, 3) == 1.254
+    assert round(VARIANTS["vit_l_16_384"].macs_per_image() / 1e9, 3) == 191.066
+    assert round(VARIANTS["vit_h_14"].macs_per_image() / 1e9, 3) == 167.295
+    assert VARIANTS["vit_l_16_384"].tokens == 577 and VARIANTS["vit_h_14"].tokens == 257
