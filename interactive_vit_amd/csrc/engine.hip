@@ -37,7 +37,7 @@ static int fail(const char* fmt, ...) {
 extern "C" const char* ivit_last_error(void) { return t_last_error.c_str(); }
 extern "C" int ivit_abi_version(void) { return IVIT_ABI_VERSION; }
 extern "C" const char* ivit_build_info(void) {
-    return "libivit gfx950 (MI355X/CDNA4) bf16-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_128x128x64, ivit_attention_bf16, "
+    return "libivit gfx950 (MI355X/CDNA4) bf16-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_{128x128,160x128,256x256}x64, ivit_attention_bf16, "
            "ivit_layernorm, ivit_unfold, ivit_tokens, ivit_transform";
 }
 
@@ -139,7 +139,7 @@ static int alloc_matrix(ivit_engine* e, Matrix* m, int rows, int cols) {
     m->rows = rows;
     m->cols = cols;
     m->ld = round_up(cols, 64);
-    return dev_alloc(e, (void**)&m->p, (size_t)round_up(rows, 128) * m->ld * sizeof(bf16_t), true);
+    return dev_alloc(e, (void**)&m->p, (size_t)round_up(rows, 256) * m->ld * sizeof(bf16_t), true);
 }
 
 static int alloc_vec(ivit_engine* e, float** v, int64_t n) { return dev_alloc(e, (void**)v, (size_t)n * sizeof(float), true); }
@@ -208,14 +208,14 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     chk(alloc_vec(e, &e->lnf_g, D)); chk(alloc_vec(e, &e->lnf_b, D));
     chk(alloc_matrix(e, &e->w_head, cfg->classes, D)); chk(alloc_vec(e, &e->b_head, cfg->classes));
 
-    const int64_t rows_tok = round_up(B * e->N, 256), rows_patch = round_up(B * e->Np, 256);
+    const int64_t rows_tok = round_up(B * e->N, 256) + 256, rows_patch = round_up(B * e->Np, 256) + 256;
     chk(dev_alloc(e, (void**)&e->patches, (size_t)rows_patch * e->Kp * 2, true));
     chk(dev_alloc(e, (void**)&e->x, (size_t)rows_tok * D * 4, true));
     chk(dev_alloc(e, (void**)&e->h, (size_t)rows_tok * D * 2, true));
     chk(dev_alloc(e, (void**)&e->qkv, (size_t)rows_tok * 3 * D * 2, true));
     chk(dev_alloc(e, (void**)&e->att, (size_t)rows_tok * D * 2, true));
     chk(dev_alloc(e, (void**)&e->u, (size_t)rows_tok * Mlp * 2, true));
-    chk(dev_alloc(e, (void**)&e->hc, (size_t)round_up(B, 256) * D * 2, true));
+    chk(dev_alloc(e, (void**)&e->hc, (size_t)(round_up(B, 256) + 256) * D * 2, true));
     chk(alloc_vec(e, &e->clsf, (int64_t)B * D));
     int64_t per_img = 0;
     for (int s = 0; s < 6 + cfg->layers; ++s)

@@ -1,0 +1,194 @@
+// bf16 MFMA GEMM kernel template for the dense projections of the ViT forward (patch embedding, QKV,
+// attention out-projection, MLP up/down, classifier head):
+//
+//     C[M,N] = A[M,K] . W[N,K]^T   (+ fused epilogue: bias, exact GELU, residual add, row remap)
+//
+// Both operands are K-contiguous ("B^T" form), which is exactly the per-lane fragment shape of
+// v_mfma_f32_16x16x32_bf16 (lane l holds 8 consecutive k of row l&15).  The product is issued
+// with W as the MFMA "A" operand and the activations as "B", so an accumulator register quad holds
+// FOUR CONSECUTIVE n of one output row: epilogue loads/stores are 8 B (bf16) / 16 B (f32) per lane.
+//
+// Tile = (WAVES_M * FM * 16) x (WAVES_N * FN * 16) x 64; each wave owns FM x FN 16x16 fragments.
+// Operand tiles are staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double
+// buffered: the loads of K-step t+1 are in flight while step t is multiplied.  The LDS image is
+// lane-linear [row][128 B]; the 16-B chunk index is XOR-swizzled with (row & 7) on the SOURCE
+// address and on the ds_read_b128 address, which makes every fragment read bank-conflict free
+// (cdna_hip_programming.md T2 / rule 21).
+#pragma once
+#include "kernels.h"
+
+namespace ivit {
+
+constexpr int GEMM_BK = 64;
+
+template <int WAVES_M_, int WAVES_N_, int FM_, int FN_>
+struct GemmTile {
+    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, FM = FM_, FN = FN_;
+    static constexpr int WAVES = WAVES_M * WAVES_N;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int BM = WAVES_M * FM * 16;
+    static constexpr int BN = WAVES_N * FN * 16;
+    static constexpr int A_BYTES = BM * GEMM_BK * 2;
+    static constexpr int W_BYTES = BN * GEMM_BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int A_PIECES = BM / 8;   // 1-KiB DMA pieces (8 rows x 128 B) per A tile
+    static constexpr int W_PIECES = BN / 8;
+    static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must be whole 8-row DMA pieces");
+};
+
+// Issue the global->LDS copies of one ROWS x 64 bf16 tile: each wave-instruction covers 8 rows x
+// 128 B.  LDS slot (row r, chunk c) receives global chunk c ^ (r & 7).
+template <int PIECES, int WAVES>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int k0,
+                                           char* lds_tile, int wave, int lane) {
+    const int r_in = lane >> 3;            // row inside the 8-row piece
+    const int chunk = (lane & 7) ^ r_in;   // (r_local & 7) == r_in because pieces are 8-row aligned
+    const bf16_t* src = g + (size_t)(row0 + r_in) * ld + k0 + chunk * 8;
+#pragma unroll
+    for (int i = 0; i < (PIECES + WAVES - 1) / WAVES; ++i) {
+        const int piece = i * WAVES + wave;
+        if (PIECES % WAVES == 0 || piece < PIECES)
+            __builtin_amdgcn_global_load_lds((const IVIT_GLOBAL void*)(src + (size_t)piece * 8 * ld),
+                                             (IVIT_LDS void*)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int r_local, int q) {
+    const int off = r_local * 128 + ((q ^ (r_local & 7)) << 4);
+    return *reinterpret_cast<const bf16x8*>(lds_tile + off);
+}
+
+template <class T>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base,
+                                              int fr, int fq) {
+    // acc[i][j][r] = C[m_base + i*16 + fr][n_base + j*16 + fq*4 + r]
+    const int epi = p.epi;
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i) {
+        const int m = m_base + i * 16 + fr;
+        if (m >= p.M) continue;
+        int orow = m;
+        int arow = 0;
+        if (p.grp_in > 0) {
+            const int grp = m / p.grp_in, within = m - grp * p.grp_in;
+            orow = grp * p.grp_out + p.grp_off + within;
+            arow = p.grp_off + within;
+        }
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) {
+            const int n = n_base + j * 16 + fq * 4;
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            const bool full = (n + 3 < p.N);
+            if (full) {
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            } else {
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
+            }
+            if (epi == EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16) {
+                bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + n;
+                if (full) {
+                    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(o) = pk;
+                } else {
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = f2bf(v[r]);
+                }
+            } else {
+                float* o = reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n;
+                if (epi == EPI_BIAS_RESID_F32) {
+                    const float* rs = p.resid + (size_t)orow * p.ldr + n;
+                    if (full) {
+                        const float4 x = *reinterpret_cast<const float4*>(rs);
+                        v[0] = x.x + v[0]; v[1] = x.y + v[1]; v[2] = x.z + v[2]; v[3] = x.w + v[3];
+                    } else {
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] = rs[r] + v[r];
+                    }
+                } else if (epi == EPI_BIAS_ROWADD_F32) {
+                    const float* ra = p.rowadd + (size_t)arow * p.ldra + n;
+                    if (full) {
+                        const float4 x = *reinterpret_cast<const float4*>(ra);
+                        v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+                    } else {
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += ra[r];
+                    }
+                }
+                if (full) {
+                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = v[r];
+                }
+            }
+        }
+    }
+}
+
+// XCD-aware, bijective block -> tile map: blocks that share an XCD (id % 8) get a contiguous run of
+// tiles, n fastest, so neighbours re-use the same A rows out of that XCD's L2.
+__device__ __forceinline__ int xcd_tile(int orig, int nwg) {
+    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+}
+
+template <class T>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / T::WAVES_N, wc = wave % T::WAVES_N;
+
+    const int tiles_n = ceil_div(p.N, T::BN);
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * T::BM;
+    const int n0 = (tile % tiles_n) * T::BN;
+
+    f32x4 acc[T::FM][T::FN];
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = p.K / GEMM_BK;
+    stage_tile<T::A_PIECES, T::WAVES>(p.A, p.lda, m0, 0, smem, wave, lane);
+    stage_tile<T::W_PIECES, T::WAVES>(p.W, p.ldw, n0, 0, smem + T::A_BYTES, wave, lane);
+
+    const int fr = lane & 15;   // fragment row (m for the A^T operand, n for the W operand)
+    const int fq = lane >> 4;   // 16-B k-chunk inside a 32-deep MFMA step
+
+    for (int t = 0; t < nt; ++t) {
+        // tile t has landed (every wave drains its own DMA, then the barrier publishes it); every
+        // wave is also past its reads of the buffer that tile t+1 is about to overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        char* cur = smem + (t & 1) * T::STAGE_BYTES;
+        if (t + 1 < nt) {
+            char* nxt = smem + ((t + 1) & 1) * T::STAGE_BYTES;
+            stage_tile<T::A_PIECES, T::WAVES>(p.A, p.lda, m0, (t + 1) * GEMM_BK, nxt, wave, lane);
+            stage_tile<T::W_PIECES, T::WAVES>(p.W, p.ldw, n0, (t + 1) * GEMM_BK, nxt + T::A_BYTES, wave, lane);
+        }
+        const char* a_tile = cur;
+        const char* w_tile = cur + T::A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[T::FM], wf[T::FN];
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) wf[j] = read_frag(w_tile, (wc * T::FN + j) * 16 + fr, kk * 4 + fq);
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i) af[i] = read_frag(a_tile, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    gemm_epilogue<T>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq);
+}
+
+}  // namespace ivit

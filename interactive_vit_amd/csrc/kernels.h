@@ -14,8 +14,8 @@ enum GemmEpilogue : int {
 };
 
 struct GemmParams {
-    const bf16_t* A; int lda;     // [M, K] bf16 row-major, rows readable up to round_up(M,128)
-    const bf16_t* W; int ldw;     // [N, K] bf16 row-major, rows readable up to round_up(N,128)
+    const bf16_t* A; int lda;     // [M, K] bf16 row-major, rows readable up to round_up(M,256)+256
+    const bf16_t* W; int ldw;     // [N, K] bf16 row-major, rows readable up to round_up(N,256)
     int M, N, K;                  // K % 64 == 0 (operands zero-padded)
     const float* bias;            // [N]
     int epi;
@@ -23,10 +23,16 @@ struct GemmParams {
     const float* resid; int ldr;  // EPI_BIAS_RESID_F32
     const float* rowadd; int ldra;  // EPI_BIAS_ROWADD_F32: [grp_out, N] table (position embedding)
     int grp_in, grp_out, grp_off;   // row remap m -> (m / grp_in) * grp_out + grp_off + m % grp_in
+    int debug;                      // microbenchmark ablations only (0 in the product): 1 = no DMA in the K loop, 2 = no MFMA
 };
 
-hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
-const char* gemm_kernel_name();
+enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_VARIANTS = 4 };
+// Operand allocations must be readable up to the tile edge: A rows up to round_up(M,256)+256,
+// W rows up to round_up(N,256) (engine.hip pads every buffer accordingly).
+hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);                       // picks the tile
+hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream);
+int gemm_pick_variant(int M, int N, int K);
+const char* gemm_variant_name(int v);
 
 // ---------------------------------------------------------------- attention (kernels_attn.hip)
 struct AttnParams {

@@ -1,190 +1,112 @@
-// bf16 MFMA GEMM for the dense projections of the ViT forward (patch embedding, QKV, attention
-// out-projection, MLP up/down, classifier head):
-//
-//     C[M,N] = A[M,K] . W[N,K]^T   (+ fused epilogue: bias, exact GELU, residual add, row remap)
-//
-// Both operands are K-contiguous ("B^T" form), which is exactly the per-lane fragment shape of
-// v_mfma_f32_16x16x32_bf16 (lane l holds 8 consecutive k of row l&15).  The product is issued
-// with W as the MFMA "A" operand and the activations as "B", so an accumulator register quad holds
-// FOUR CONSECUTIVE n of one output row: epilogue loads/stores are 8 B (bf16) / 16 B (f32) per lane.
-//
-// Tile 128x128x64, 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64 = 4x4 MFMA fragments.
-// Operand tiles are staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double
-// buffered: the loads of K-step t+1 are in flight while step t is multiplied.  The LDS image is
-// lane-linear [row][128 B]; the 16-B chunk index is XOR-swizzled with (row & 7) on the SOURCE
-// address and on the ds_read_b128 address, which makes every fragment read bank-conflict free
-// (cdna_hip_programming.md T2 / rule 21).
-#include "kernels.h"
+// Instantiations of the bf16 MFMA GEMM template (gemm_kernel.h) and the per-shape tile choice.
+#include "gemm256_kernel.h"
+#include <cmath>
 
 namespace ivit {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int GEMM_THREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A then W
-constexpr int GEMM_LDS_BYTES = 2 * STAGE_BYTES;  // double buffered: 64 KiB -> 2 blocks per CU
+using Tile128 = GemmTile<2, 2, 4, 4>;   // 128 x 128, 4 waves (64x64 each), 64 KiB LDS, 2 blocks/CU
+using Tile160 = GemmTile<2, 2, 5, 4>;   // 160 x 128, 4 waves (80x64 each), 72 KiB LDS, 2 blocks/CU
+using Tile256 = GemmTile<2, 4, 8, 4>;   // 256 x 256, 8 waves (128x64 each), 128 KiB LDS, 1 block/CU
 
-// Issue the global->LDS copies of one 128x64 bf16 tile (16 KiB): 4 wave-instructions per wave,
-// each covering 8 rows x 128 B.  LDS slot (row r, chunk c) receives global chunk c ^ (r & 7).
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int k0,
-                                           char* lds_tile, int wave, int lane) {
-    const int r_in = lane >> 3;                       // row inside the 8-row piece
-    const int chunk = (lane & 7) ^ r_in;              // (r_local & 7) == r_in because pieces are 8-row aligned
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = i * 4 + wave;               // 0..15
-        const int r_local = piece * 8 + r_in;
-        const bf16_t* src = g + (size_t)(row0 + r_local) * ld + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((const IVIT_GLOBAL void*)src,
-                                         (IVIT_LDS void*)(lds_tile + piece * 1024), 16, 0, 0);
-    }
-}
-
-__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int r_local, int q) {
-    const int off = r_local * 128 + ((q ^ (r_local & 7)) << 4);
-    return *reinterpret_cast<const bf16x8*>(lds_tile + off);
-}
-
-__global__ __launch_bounds__(GEMM_THREADS, 2) void ivit_gemm_bf16_128x128x64(GemmParams p) {
+__global__ __launch_bounds__(Tile128::THREADS, 2) void ivit_gemm_bf16_128x128x64(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-
-    // XCD-aware, bijective block -> tile map: blocks that share an XCD (id % 8) get a contiguous run
-    // of tiles, n fastest, so neighbours re-use the same A rows out of that XCD's L2.
-    const int tiles_n = ceil_div(p.N, BN);
-    const int nwg = gridDim.x;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
-    const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nt = p.K / BK;
-    stage_tile(p.A, p.lda, m0, 0, smem, wave, lane);
-    stage_tile(p.W, p.ldw, n0, 0, smem + TILE_BYTES, wave, lane);
-
-    const int fr = lane & 15;   // fragment row (m for A^T operand, n for W operand)
-    const int fq = lane >> 4;   // 16-B k-chunk inside a 32-deep MFMA step
-
-    for (int t = 0; t < nt; ++t) {
-        // tile t has landed (every wave drains its own DMA, then the barrier publishes it); every
-        // wave is also past its reads of the buffer that tile t+1 is about to overwrite
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        char* cur = smem + (t & 1) * STAGE_BYTES;
-        if (t + 1 < nt) {
-            char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
-            stage_tile(p.A, p.lda, m0, (t + 1) * BK, nxt, wave, lane);
-            stage_tile(p.W, p.ldw, n0, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
-        }
-        const char* a_tile = cur;
-        const char* w_tile = cur + TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], wf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag(a_tile, wr * 64 + i * 16 + fr, kk * 4 + fq);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = read_frag(w_tile, wc * 64 + j * 16 + fr, kk * 4 + fq);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    // ---------------- epilogue: acc[i][j][r] = C[m0 + wr*64 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
-    const int epi = p.epi;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + i * 16 + fr;
-        if (m >= p.M) continue;
-        int orow = m;
-        int arow = 0;
-        if (p.grp_in > 0) {
-            const int grp = m / p.grp_in, within = m - grp * p.grp_in;
-            orow = grp * p.grp_out + p.grp_off + within;
-            arow = p.grp_off + within;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + fq * 4;
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            const bool full = (n + 3 < p.N);
-            if (full) {
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            } else {
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
-            }
-            if (epi == EPI_BIAS_GELU_BF16) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16) {
-                bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + n;
-                if (full) {
-                    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(o) = pk;
-                } else {
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = f2bf(v[r]);
-                }
-            } else {
-                float* o = reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n;
-                if (epi == EPI_BIAS_RESID_F32) {
-                    const float* rs = p.resid + (size_t)orow * p.ldr + n;
-                    if (full) {
-                        const float4 x = *reinterpret_cast<const float4*>(rs);
-                        v[0] = x.x + v[0]; v[1] = x.y + v[1]; v[2] = x.z + v[2]; v[3] = x.w + v[3];
-                    } else {
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] = rs[r] + v[r];
-                    }
-                } else if (epi == EPI_BIAS_ROWADD_F32) {
-                    const float* ra = p.rowadd + (size_t)arow * p.ldra + n;
-                    if (full) {
-                        const float4 x = *reinterpret_cast<const float4*>(ra);
-                        v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
-                    } else {
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += ra[r];
-                    }
-                }
-                if (full) {
-                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = v[r];
-                }
-            }
-        }
-    }
+    gemm_body<Tile128>(p, smem);
+}
+__global__ __launch_bounds__(Tile160::THREADS, 2) void ivit_gemm_bf16_160x128x64(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<Tile160>(p, smem);
+}
+__global__ __launch_bounds__(Tile256::THREADS, 2) void ivit_gemm_bf16_256x256x64(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<Tile256>(p, smem);
 }
 
-const char* gemm_kernel_name() { return "ivit_gemm_bf16_128x128x64"; }
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_pipe(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256_body<0>(p, smem);
+}
+#ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): timing ablations, wrong results
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_256pipe_nodma(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256_body<1>(p, smem);
+}
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_256pipe_nomfma(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256_body<2>(p, smem);
+}
+#endif
 
-hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
-    if (p.M <= 0 || p.N <= 0) return hipSuccess;
-    if (p.K <= 0 || p.K % BK != 0) return hipErrorInvalidValue;
-    if ((p.lda % 8) || (p.ldw % 8)) return hipErrorInvalidValue;   // 16-B aligned rows for the DMA
-    if ((p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
-    static bool attr_set = false;
+const char* gemm_variant_name(int v) {
+    switch (v) {
+        case GEMM_TILE_128: return "ivit_gemm_bf16_128x128x64";
+        case GEMM_TILE_160: return "ivit_gemm_bf16_160x128x64";
+        case GEMM_TILE_256: return "ivit_gemm_bf16_256x256x64";
+        case GEMM_TILE_256P: return "ivit_gemm_bf16_256x256x64_pipe";
+    }
+    return "?";
+}
+
+template <class T, class K>
+static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;   // one process drives one GPU
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_gemm_bf16_128x128x64),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    hipLaunchKernelGGL(ivit_gemm_bf16_128x128x64, dim3(tiles), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, p);
+    const int tiles = ceil_div(p.M, T::BM) * ceil_div(p.N, T::BN);
+    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(T::THREADS), T::LDS_BYTES, stream, p);
     return hipGetLastError();
+}
+
+// Tile choice, from tools/gemm_bench on MI355X (ViT-B/16 shapes, M = 12608; TFLOP/s):
+//                       128x128   160x128   256x256   256x256_pipe
+//   N=2304 K= 768 (qkv)   643       640       614        620
+//   N= 768 K= 768 (proj)  363       462       333        326
+//   N=3072 K= 768 (mlp1)  498       512       450        386      (with the GELU epilogue)
+//   N= 768 K=3072 (mlp2)  671       885       645        644
+// The two-workgroups-per-CU tiles overlap one tile's epilogue with the other's main loop; the
+// 256x256 tiles (one workgroup per CU, lockstep rounds) pay their output burst serially and lose
+// despite half the L2->LDS traffic.  So: 160x128 unless the 128x128 grid fills the 512 slots better.
+int gemm_pick_variant(int M, int N, int K) {
+    (void)K;
+    struct Cand { int v, bm, bn; double speed; };
+    static const Cand cands[] = {
+        {GEMM_TILE_160, Tile160::BM, Tile160::BN, 1.03},
+        {GEMM_TILE_128, Tile128::BM, Tile128::BN, 1.00},
+    };
+    int best = GEMM_TILE_160;
+    double best_t = 1e300;
+    for (const Cand& c : cands) {
+        const double tiles = (double)ceil_div(M, c.bm) * ceil_div(N, c.bn);
+        const double rounds = std::ceil(tiles / 512.0);                 // 256 CUs x 2 resident workgroups
+        const double t = rounds * c.bm * c.bn / c.speed;
+        if (t < best_t) { best_t = t; best = c.v; }
+    }
+    return best;
+}
+
+hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream) {
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if (p.K <= 0 || p.K % GEMM_BK != 0) return hipErrorInvalidValue;
+    if ((p.lda % 8) || (p.ldw % 8)) return hipErrorInvalidValue;   // 16-B aligned rows for the DMA
+    if ((p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
+    switch (variant) {
+        case GEMM_TILE_128: return launch_tile<Tile128>(ivit_gemm_bf16_128x128x64, p, stream);
+        case GEMM_TILE_160: return launch_tile<Tile160>(ivit_gemm_bf16_160x128x64, p, stream);
+        case GEMM_TILE_256: return launch_tile<Tile256>(ivit_gemm_bf16_256x256x64, p, stream);
+        case GEMM_TILE_256P:
+#ifdef IVIT_GEMM_ABLATIONS
+            if (p.debug == 1) return launch_tile<Tile256P>(ivit_gemm_256pipe_nodma, p, stream);
+            if (p.debug == 2) return launch_tile<Tile256P>(ivit_gemm_256pipe_nomfma, p, stream);
+#endif
+            return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_pipe, p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
+    return launch_gemm_variant(p, gemm_pick_variant(p.M, p.N, p.K), stream);
 }
 
 }  // namespace ivit

@@ -1,0 +1,110 @@
+// Standalone A/B microbenchmark of the GEMM tile variants on the ViT shapes (one process, interleaved
+// rounds, random data - cdna_hip_programming.md rules 24/25).  Build: see tools/build_tools.sh.
+#include "../interactive_vit_amd/csrc/kernels.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+using namespace ivit;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void naive_rows(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, float* out, int N, int K, const int* rows, int nrows) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (n >= N || r >= nrows) return;
+    const int m = rows[r];
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += bf2f(A[(size_t)m * lda + k]) * bf2f(W[(size_t)n * ldw + k]);
+    out[(size_t)r * N + n] = acc + bias[n];
+}
+
+static bf16_t h_f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (bf16_t)(u >> 16); }
+
+int main(int argc, char** argv) {
+    const int Mfull = argc > 1 ? atoi(argv[1]) : 64 * 197;
+    const int only_shape = argc > 2 ? atoi(argv[2]) : -1;      // -1: all shapes
+    const unsigned vmask = argc > 3 ? (unsigned)strtoul(argv[3], nullptr, 0) : 0xffffffffu;
+    const int rounds = argc > 4 ? atoi(argv[4]) : 7;
+    const int debug = argc > 5 ? atoi(argv[5]) : 0;
+    struct Shape { const char* name; int M, N, K, epi; };
+    std::vector<Shape> shapes = {
+        {"qkv   ", Mfull, 2304, 768, EPI_BIAS_BF16}, {"proj  ", Mfull, 768, 768, EPI_BIAS_RESID_F32},
+        {"mlp1  ", Mfull, 3072, 768, EPI_BIAS_GELU_BF16}, {"mlp2  ", Mfull, 768, 3072, EPI_BIAS_RESID_F32},
+        {"patch ", 64 * 196, 768, 768, EPI_BIAS_F32}, {"mlp1ng", Mfull, 3072, 768, EPI_BIAS_BF16},
+    };
+    const int maxM = round_up(Mfull, 256) + 256, maxN = 3072, maxK = 3072;
+    std::mt19937 rng(1);
+    std::uniform_real_distribution<float> u(-1.f, 1.f);
+    std::vector<bf16_t> hA((size_t)maxM * maxK), hW((size_t)maxN * maxK);
+    for (auto& v : hA) v = h_f2bf(u(rng));
+    for (auto& v : hW) v = h_f2bf(u(rng) * 0.05f);
+    std::vector<float> hb(maxN);
+    for (auto& v : hb) v = u(rng);
+    bf16_t *dA, *dW; float *db, *dout, *dres, *dref; int* drows;
+    CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&db, maxN * 4));
+    CK(hipMalloc(&dout, (size_t)maxM * maxN * 4)); CK(hipMalloc(&dres, (size_t)maxM * maxN * 4));
+    const int NR = 64;
+    CK(hipMalloc(&dref, (size_t)NR * maxN * 4)); CK(hipMalloc(&drows, NR * 4));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), maxN * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dres, 0, (size_t)maxM * maxN * 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+
+    int shape_idx = -1;
+    for (const Shape& s : shapes) {
+        ++shape_idx;
+        if (only_shape >= 0 && shape_idx != only_shape) continue;
+        GemmParams p{};
+        p.A = dA; p.lda = s.K; p.W = dW; p.ldw = s.K; p.M = s.M; p.N = s.N; p.K = s.K; p.bias = db; p.epi = s.epi;
+        p.out = dout; p.ldo = s.N; p.resid = dres; p.ldr = s.N; p.debug = debug;
+        // correctness on sampled rows (epilogue F32 so the values are comparable)
+        std::vector<int> rows(NR);
+        for (int i = 0; i < NR; ++i) rows[i] = (int)((long long)i * (s.M - 1) / (NR - 1));
+        CK(hipMemcpy(drows, rows.data(), NR * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(naive_rows, dim3(ceil_div(s.N, 256), NR), dim3(256), 0, 0, dA, s.K, dW, s.K, db, dref, s.N, s.K, drows, NR);
+        std::vector<float> href((size_t)NR * s.N), hout;
+        CK(hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost));
+        printf("%s M=%d N=%d K=%d pick=%s\n", s.name, s.M, s.N, s.K, gemm_variant_name(gemm_pick_variant(s.M, s.N, s.K)));
+        double best[GEMM_VARIANTS]; std::vector<double> times[GEMM_VARIANTS];
+        for (int v = 0; v < GEMM_VARIANTS; ++v) {
+            if (!((vmask >> v) & 1)) continue;
+            GemmParams q = p; q.epi = EPI_BIAS_F32; q.debug = 0;
+            CK(hipMemset(dout, 0xff, (size_t)s.M * s.N * 4));
+            CK(launch_gemm_variant(q, v, 0));
+            CK(hipDeviceSynchronize());
+            double maxerr = 0, maxref = 0;
+            hout.resize((size_t)s.N);
+            for (int i = 0; i < NR; ++i) {
+                CK(hipMemcpy(hout.data(), dout + (size_t)rows[i] * s.N, s.N * 4, hipMemcpyDeviceToHost));
+                for (int n = 0; n < s.N; ++n) { maxerr = std::max(maxerr, (double)fabsf(hout[n] - href[(size_t)i * s.N + n])); maxref = std::max(maxref, (double)fabsf(href[(size_t)i * s.N + n])); }
+            }
+            printf("   %-28s check: max err %.3e (max ref %.3f) %s\n", gemm_variant_name(v), maxerr, maxref, maxerr <= 1e-3 * maxref ? "OK" : "MISMATCH");
+        }
+        for (int round = 0; round < rounds; ++round)
+            for (int v = 0; v < GEMM_VARIANTS; ++v) {
+                if (!((vmask >> v) & 1)) continue;
+                const int iters = rounds >= 7 ? 10 : 2;
+                CK(launch_gemm_variant(p, v, 0));
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < iters; ++i) CK(launch_gemm_variant(p, v, 0));
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                times[v].push_back(ms / iters);
+            }
+        for (int v = 0; v < GEMM_VARIANTS; ++v) {
+            if (!((vmask >> v) & 1)) continue;
+            std::sort(times[v].begin(), times[v].end());
+            const double med = times[v][times[v].size() / 2], mn = times[v][0];
+            best[v] = med;
+            const double fl = 2.0 * s.M * s.N * s.K;
+            printf("   %-28s median %8.2f us  %7.1f TF/s   (min %8.2f us %7.1f TF/s)\n", gemm_variant_name(v), med * 1e3, fl / med / 1e9, mn * 1e3, fl / mn / 1e9);
+        }
+    }
+    return 0;
+}
