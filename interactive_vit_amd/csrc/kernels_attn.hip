@@ -1,44 +1,52 @@
-// Multi-head self-attention core for ViT token counts (17 .. 608 keys), head dim 64:
+// Multi-head self-attention core for ViT token counts (up to 608 keys), head dim 64:
 //
 //     out[b, q, h*64 + d] = sum_key softmax_key(scale * Q[q].K[key]) * V[key][d]
 //
-// One workgroup = 4 waves = 64 queries of one (image, head); each wave owns 16 queries.  All keys
-// of the head fit in LDS (197 keys: 28 KiB K + 29 KiB V^T), so the softmax is a single exact pass
-// with every score of the wave's 16 queries held in registers - no online rescaling is needed at
-// these sequence lengths.
-//
-// Both contractions run on v_mfma_f32_16x16x32_bf16 with the key index on the accumulator ROW:
-//   S^T = K . Q^T    (A operand = K rows from LDS, B operand = the wave's Q fragments)
+// One workgroup = one (image, head) [or a 256-query slice of it for long sequences]; K and V of the
+// head are staged ONCE into LDS with plain 16-byte copies (197 keys: 28 KiB + 28 KiB, two workgroups
+// per CU).  Each wave owns QB x 16 queries.  All keys fit on chip, so the softmax is a single exact
+// pass with every score of the wave's queries held in registers - no online rescaling at these
+// lengths.  Both contractions run on v_mfma_f32_16x16x32_bf16 with the key index on the
+// accumulator ROW:
+//   S^T = K . Q^T    A operand = K rows (ds_read_b128, chunk XOR-swizzled by key & 7), B = Q fragments
 //         -> lane (fr = lane&15, g = lane>>4) holds S[q = fr][key = 16 f + 4 g + j], j = 0..3
-//   O^T = V^T . P^T  (A operand = V^T rows from LDS, B operand = P straight from those registers)
+//   O^T = V^T . P^T  A operand = V^T fragments, B operand = P straight from those registers
 //         -> lane holds O[q = fr][d = 16 dblk + 4 g + j]: an 8-byte bf16 store per fragment
-// The k order inside an MFMA step may be any permutation as long as both operands agree, so the
-// P registers of fragments 2s and 2s+1 are used as the 8 k-slots of step s without lane movement;
-// V^T is read with the matching key order (two 8-byte reads per fragment).
-// Softmax statistics are fp32; the row reductions are wavefront shuffles across the 4 lane groups.
+// The k order inside an MFMA step may be any permutation as long as both operands agree, so the P
+// registers of score fragments 2s and 2s+1 ARE the 8 k-slots of step s (slot 8g + j' = key
+// 32 s + 16 (j'>>2) + 4 g + (j'&3)), with no lane movement.  V stays ROW-MAJOR in LDS ([key][64 d],
+// 128-B rows) and is transposed on the fly by ds_read_b64_tr_b16: per 16-lane group the instruction
+// reads a 4-key x 16-d block and hands lane i the 4 keys of column d0 + i - exactly the V^T fragment
+// half (keys 32 s + 4 g .. +3, then +16).  V's 16-B chunks are XOR-swizzled by ((key >> 1) & 3) << 1,
+// which makes those reads bank-conflict free.  K and V fragments are shared by the wave's QB query
+// blocks.  Softmax statistics are fp32; row max / sum are wavefront shuffles across the 4 lane groups.
 #include "kernels.h"
 
 namespace ivit {
 
 constexpr int ATT_DH = 64;
-constexpr int ATT_THREADS = 256;
-constexpr int ATT_QPB = 64;  // queries per block
 
-template <int NKF>
+template <int NKF, int QB>
 struct AttLayout {
     static constexpr int KEYS = NKF * 16;
-    static constexpr int K_BYTES = KEYS * ATT_DH * 2;
-    static constexpr int VT_STRIDE_DW = NKF * 8 + 4;  // dwords per V^T row; == 4 (mod 8): conflict-free b64 reads
-    static constexpr int VT_BYTES = ATT_DH * VT_STRIDE_DW * 4;
-    static constexpr int LDS_BYTES = K_BYTES + VT_BYTES;
+    static constexpr int K_BYTES = KEYS * 128;
+    static constexpr int V_BYTES = KEYS * 128;
+    static constexpr int LDS_BYTES = K_BYTES + V_BYTES;
+    static constexpr int QPW = QB * 16;   // queries per wave
 };
 
-template <int NKF>
-__global__ __launch_bounds__(ATT_THREADS) void ivit_attention_bf16(AttnParams p) {
-    using L = AttLayout<NKF>;
+__device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((IVIT_LDS s16x4*)p);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+template <int NKF, int QB>
+__global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
+    using L = AttLayout<NKF, QB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
-    char* vt_lds = smem + L::K_BYTES;
+    char* v_lds = smem + L::K_BYTES;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -50,125 +58,149 @@ __global__ __launch_bounds__(ATT_THREADS) void ivit_attention_bf16(AttnParams p)
     const bf16_t* qkv = p.qkv;
     const int ld = p.ldqkv;
 
-    // ---- stage K (row-major, 16-B chunks XOR-swizzled by key&7) and V^T (key-contiguous rows)
-    for (int c = threadIdx.x; c < L::KEYS * 8; c += ATT_THREADS) {
+    // ---- stage K and V (row-major, 16-B chunks; rows >= N are zero: 0 * garbage must not be NaN)
+    for (int c = threadIdx.x; c < L::KEYS * 8; c += blockDim.x) {
         const int key = c >> 3, ch = c & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (key < N) v = *reinterpret_cast<const u32x4*>(qkv + (row0 + key) * ld + D + h * ATT_DH + ch * 8);
-        *reinterpret_cast<u32x4*>(k_lds + key * 128 + ((ch ^ (key & 7)) << 4)) = v;
-    }
-    for (int c = threadIdx.x; c < L::KEYS * 8; c += ATT_THREADS) {
-        const int key = c % L::KEYS, ch = c / L::KEYS;   // lanes run over keys: conflict-light 2-byte writes
-        u32x4 v = {0u, 0u, 0u, 0u};                       // keys >= N must be finite (0 * NaN would poison PV)
-        if (key < N) v = *reinterpret_cast<const u32x4*>(qkv + (row0 + key) * ld + 2 * D + h * ATT_DH + ch * 8);
-        bf16_t* dst = reinterpret_cast<bf16_t*>(vt_lds) + key;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dst[(size_t)(ch * 8 + 2 * i) * (L::VT_STRIDE_DW * 2)] = (bf16_t)(v[i] & 0xffffu);
-            dst[(size_t)(ch * 8 + 2 * i + 1) * (L::VT_STRIDE_DW * 2)] = (bf16_t)(v[i] >> 16);
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (key < N) {
+            const bf16_t* src = qkv + (row0 + key) * ld + h * ATT_DH + ch * 8;
+            kv = *reinterpret_cast<const u32x4*>(src + D);
+            vv = *reinterpret_cast<const u32x4*>(src + 2 * D);
         }
+        *reinterpret_cast<u32x4*>(k_lds + key * 128 + ((ch ^ (key & 7)) << 4)) = kv;
+        *reinterpret_cast<u32x4*>(v_lds + key * 128 + ((ch ^ (((key >> 1) & 3) << 1)) << 4)) = vv;
     }
     __syncthreads();
 
-    const int q0 = blockIdx.x * ATT_QPB + wave * 16;
+    const int q0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * L::QPW;
     if (q0 >= N) return;  // whole wave idle (after the only barrier)
 
-    // ---- Q fragments (B operand): lane holds Q[q0+fr][kk*32 + 8g .. +7]
-    const int qrow = min(q0 + fr, N - 1);
-    bf16x8 qf[2];
+    // ---- Q fragments (B operand): lane holds Q[q0 + 16c + fr][kk*32 + 8g .. +7]
+    bf16x8 qf[QB][2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-        qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8);
+    for (int c = 0; c < QB; ++c) {
+        const int qrow = min(q0 + c * 16 + fr, N - 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            qf[c][kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8);
+    }
 
     // ---- S^T = K Q^T
-    f32x4 s[NKF];
+    f32x4 s[QB][NKF];
 #pragma unroll
     for (int f = 0; f < NKF; ++f) {
         const int key = f * 16 + fr;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf[2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + key * 128 + (((kk * 4 + g) ^ (key & 7)) << 4));
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], a, 0, 0, 0);
+        for (int kk = 0; kk < 2; ++kk)
+            kf[kk] = *reinterpret_cast<const bf16x8*>(k_lds + key * 128 + (((kk * 4 + g) ^ (key & 7)) << 4));
+#pragma unroll
+        for (int c = 0; c < QB; ++c) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[c][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[c][1], a, 0, 0, 0);
+            s[c][f] = a;
         }
-        s[f] = a;
     }
 
-    // ---- softmax over keys (row q = fr lives in this lane's registers and the 3 other lane groups)
-    float mx = -INFINITY;
+    // ---- softmax over keys; only the last two fragments can hold padded keys (KEYS - N < 32)
+    const float cexp = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*scale*log2 e)
+    float inv[QB];
 #pragma unroll
-    for (int f = 0; f < NKF; ++f)
+    for (int c = 0; c < QB; ++c) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int key = f * 16 + g * 4 + j;
-            const float v = (key < N) ? s[f][j] : -INFINITY;
-            s[f][j] = v;
-            mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float c = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*scale*log2 e)
-    const float mc = mx * c;
-    float sum = 0.f;
+        for (int f = NKF - 2; f < NKF; ++f)
 #pragma unroll
-    for (int f = 0; f < NKF; ++f)
+            for (int j = 0; j < 4; ++j)
+                if (f * 16 + g * 4 + j >= N) s[c][f][j] = -INFINITY;
+        float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(s[f][j], c, -mc));
-            s[f][j] = e;
-            sum += e;
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+        for (int f = 0; f < NKF; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[c][f][0], s[c][f][1]), fmaxf(s[c][f][2], s[c][f][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc = mx * cexp;
+        float sum = 0.f;
+#pragma unroll
+        for (int f = 0; f < NKF; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[c][f][j], cexp, -mc));
+                s[c][f][j] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        inv[c] = 1.0f / sum;
+    }
 
     // ---- O^T = V^T P^T
-    f32x4 o[4];
+    f32x4 o[QB][4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < QB; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // transposed-read addressing: lane i = 4q + p of its 16-lane group supplies &V[key0 + q][d0 + 4p]
+    const int tq = fr >> 2, tp = fr & 3;
 #pragma unroll
     for (int st = 0; st < NKF / 2; ++st) {
-        const f32x4 p0 = s[2 * st], p1 = s[2 * st + 1];
-        union { bf16x8 v; unsigned int u[4]; } pf;
-        pf.u[0] = pack_bf16x2(p0[0], p0[1]);
-        pf.u[1] = pack_bf16x2(p0[2], p0[3]);
-        pf.u[2] = pack_bf16x2(p1[0], p1[1]);
-        pf.u[3] = pack_bf16x2(p1[2], p1[3]);
+        bf16x8 pf[QB];
+#pragma unroll
+        for (int c = 0; c < QB; ++c) {
+            const f32x4 p0 = s[c][2 * st], p1 = s[c][2 * st + 1];
+            union { bf16x8 v; unsigned int u[4]; } pk;
+            pk.u[0] = pack_bf16x2(p0[0], p0[1]);
+            pk.u[1] = pack_bf16x2(p0[2], p0[3]);
+            pk.u[2] = pack_bf16x2(p1[0], p1[1]);
+            pk.u[3] = pack_bf16x2(p1[2], p1[3]);
+            pf[c] = pk.v;
+        }
+        const int key_lo = 32 * st + 4 * g + tq;       // first half of the k-slots; second half = +16 keys
+        const int sw_lo = ((key_lo >> 1) & 3) << 1, sw_hi = (((key_lo + 16) >> 1) & 3) << 1;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const char* vrow = vt_lds + (size_t)(d * 16 + fr) * (L::VT_STRIDE_DW * 4) + (32 * st + 4 * g) * 2;
-            union { bf16x8 v; u32x2 h2[2]; } vf;
-            vf.h2[0] = *reinterpret_cast<const u32x2*>(vrow);
-            vf.h2[1] = *reinterpret_cast<const u32x2*>(vrow + 32);
-            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[d], 0, 0, 0);
+            const int chunk = d * 2 + (tp >> 1);       // 16-B chunk of columns d*16 + 4*tp
+            const char* lo = v_lds + key_lo * 128 + ((chunk ^ sw_lo) << 4) + (tp & 1) * 8;
+            const char* hi = v_lds + (key_lo + 16) * 128 + ((chunk ^ sw_hi) << 4) + (tp & 1) * 8;
+            union { bf16x8 v; bf16x4 h2[2]; } vf;
+            vf.h2[0] = lds_read_tr16(lo);
+            vf.h2[1] = lds_read_tr16(hi);
+#pragma unroll
+            for (int c = 0; c < QB; ++c) o[c][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[c], o[c][d], 0, 0, 0);
         }
     }
 
-    // ---- normalise and store: lane holds O[q0+fr][16 d + 4 g .. +3]
-    if (q0 + fr < N) {
-        bf16_t* orow = p.out + (row0 + q0 + fr) * p.ldo + h * ATT_DH + g * 4;
+    // ---- normalise and store: lane holds O[q0 + 16c + fr][16 d + 4 g .. +3]
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            u32x2 pk = {pack_bf16x2(o[d][0] * inv, o[d][1] * inv), pack_bf16x2(o[d][2] * inv, o[d][3] * inv)};
-            *reinterpret_cast<u32x2*>(orow + d * 16) = pk;
+    for (int c = 0; c < QB; ++c) {
+        const int q = q0 + c * 16 + fr;
+        if (q < N) {
+            bf16_t* orow = p.out + (row0 + q) * p.ldo + h * ATT_DH + g * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                u32x2 pk = {pack_bf16x2(o[c][d][0] * inv[c], o[c][d][1] * inv[c]),
+                            pack_bf16x2(o[c][d][2] * inv[c], o[c][d][3] * inv[c])};
+                *reinterpret_cast<u32x2*>(orow + d * 16) = pk;
+            }
         }
     }
 }
 
 bool attention_supported(int tokens, int head_dim) { return head_dim == ATT_DH && tokens >= 1 && tokens <= 38 * 16; }
 
-template <int NKF>
+template <int NKF, int QB>
 static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
-    using L = AttLayout<NKF>;
+    using L = AttLayout<NKF, QB>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<NKF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<NKF, QB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(ceil_div(p.tokens, ATT_QPB), p.heads, p.batch);
-    hipLaunchKernelGGL(ivit_attention_bf16<NKF>, grid, dim3(ATT_THREADS), L::LDS_BYTES, stream, p);
+    const int waves_needed = ceil_div(p.tokens, L::QPW);
+    const int wpb = waves_needed < 8 ? waves_needed : 8;          // waves per workgroup
+    dim3 grid(ceil_div(waves_needed, wpb), p.heads, p.batch);
+    hipLaunchKernelGGL((ivit_attention_bf16<NKF, QB>), grid, dim3(wpb * 64), L::LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 
@@ -176,13 +208,13 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (!attention_supported(p.tokens, p.head_dim)) return hipErrorInvalidValue;
     if ((p.ldqkv % 8) || (p.ldo % 4)) return hipErrorInvalidValue;
     const int nkf = round_up(ceil_div(p.tokens, 16), 2);
-    if (nkf <= 2) return launch_nkf<2>(p, stream);
-    if (nkf <= 4) return launch_nkf<4>(p, stream);
-    if (nkf <= 8) return launch_nkf<8>(p, stream);
-    if (nkf <= 14) return launch_nkf<14>(p, stream);   // 197 tokens (224^2 / 16)
-    if (nkf <= 18) return launch_nkf<18>(p, stream);   // 257 tokens (224^2 / 14)
-    if (nkf <= 26) return launch_nkf<26>(p, stream);
-    return launch_nkf<38>(p, stream);                  // 577 tokens (384^2 / 16)
+    if (nkf <= 2) return launch_nkf<2, 2>(p, stream);
+    if (nkf <= 4) return launch_nkf<4, 2>(p, stream);
+    if (nkf <= 8) return launch_nkf<8, 2>(p, stream);
+    if (nkf <= 14) return launch_nkf<14, 2>(p, stream);   // 197 tokens (224^2 / 16): 7 waves x 32 queries
+    if (nkf <= 18) return launch_nkf<18, 2>(p, stream);   // 257 tokens (224^2 / 14)
+    if (nkf <= 26) return launch_nkf<26, 1>(p, stream);
+    return launch_nkf<38, 1>(p, stream);                  // 577 tokens (384^2 / 16): 16 queries per wave
 }
 
 }  // namespace ivit
