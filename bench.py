@@ -182,7 +182,7 @@ def main():
         g = classes["gemm"]
         avg_us = g["ms"] * 1e3 / max(1, g["launches"])
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "ivit_gemm_bf16_128x128x64", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+        roofline = {"bound": "mfma", "kernel": "ivit_gemm_bf16_160x128x64", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": g["launches"] // args.steps, "avg_launch_us": round(avg_us, 2),
                     "algorithmic_gflop_per_step": round(g["flops"] / args.steps / 1e9, 2),

@@ -161,10 +161,10 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, char* smem) {
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
 
-    const int tiles_n = ceil_div(p.N, T::BN);
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * T::BM;
-    const int n0 = (tile % tiles_n) * T::BN;
+    int tm, tn;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
+    const int m0 = tm * T::BM;
+    const int n0 = tn * T::BN;
 
     G256Ctx c;
     c.smem = smem; c.wave = wave; c.lda = p.lda; c.ldw = p.ldw;

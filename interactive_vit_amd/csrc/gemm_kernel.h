@@ -59,15 +59,32 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int r_local, i
     return *reinterpret_cast<const bf16x8*>(lds_tile + off);
 }
 
-template <class T>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base,
-                                              int fr, int fq) {
-    // acc[i][j][r] = C[m_base + i*16 + fr][n_base + j*16 + fq*4 + r]
+// Epilogue.  acc[i][j][r] = C[m_base + i*16 + fr][n_base + j*16 + fq*4 + r].
+// Interior tiles (every row < M, every column quad < N - the wave-uniform common case) take a
+// branch-free path: the bias quads are loaded once per wave, and with no control flow between them
+// the residual loads / stores of many fragments are in flight together.  (With a branch per
+// fragment hipcc emitted load -> s_waitcnt vmcnt(0) -> store 32 times in a row, each paying a full
+// memory latency: ~10 us per 256x256 tile.)  Edge tiles take the guarded path.
+template <class T, bool INTERIOR>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base,
+                                                   int n_base, int fr, int fq) {
     const int epi = p.epi;
+    float4 bias4[T::FN];
+#pragma unroll
+    for (int j = 0; j < T::FN; ++j) {
+        const int n = n_base + j * 16 + fq * 4;
+        if (INTERIOR || n + 3 < p.N) {
+            bias4[j] = *reinterpret_cast<const float4*>(p.bias + n);
+        } else {
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) b[r] = p.bias[n + r];
+            bias4[j] = make_float4(b[0], b[1], b[2], b[3]);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < T::FM; ++i) {
         const int m = m_base + i * 16 + fr;
-        if (m >= p.M) continue;
+        if (!INTERIOR && m >= p.M) continue;
         int orow = m;
         int arow = 0;
         if (p.grp_in > 0) {
@@ -75,18 +92,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             orow = grp * p.grp_out + p.grp_off + within;
             arow = p.grp_off + within;
         }
+        float4 extra[T::FN];   // residual / row-add operand of this row, all column fragments at once
+        if (INTERIOR && (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_ROWADD_F32)) {
+            const float* src = (epi == EPI_BIAS_RESID_F32) ? p.resid + (size_t)orow * p.ldr : p.rowadd + (size_t)arow * p.ldra;
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) extra[j] = *reinterpret_cast<const float4*>(src + n_base + j * 16 + fq * 4);
+        }
 #pragma unroll
         for (int j = 0; j < T::FN; ++j) {
             const int n = n_base + j * 16 + fq * 4;
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            const bool full = (n + 3 < p.N);
-            if (full) {
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            } else {
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
-            }
+            if (!INTERIOR && n >= p.N) continue;
+            float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+            const bool full = INTERIOR || (n + 3 < p.N);
             if (epi == EPI_BIAS_GELU_BF16) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -101,7 +118,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 }
             } else {
                 float* o = reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n;
-                if (epi == EPI_BIAS_RESID_F32) {
+                if (INTERIOR) {
+                    if (epi == EPI_BIAS_RESID_F32) {           // resid + (acc + bias)
+                        v[0] = extra[j].x + v[0]; v[1] = extra[j].y + v[1]; v[2] = extra[j].z + v[2]; v[3] = extra[j].w + v[3];
+                    } else if (epi == EPI_BIAS_ROWADD_F32) {   // (acc + bias) + rowadd
+                        v[0] += extra[j].x; v[1] += extra[j].y; v[2] += extra[j].z; v[3] += extra[j].w;
+                    }
+                } else if (epi == EPI_BIAS_RESID_F32) {
                     const float* rs = p.resid + (size_t)orow * p.ldr + n;
                     if (full) {
                         const float4 x = *reinterpret_cast<const float4*>(rs);
@@ -128,11 +151,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
 }
 
+template <class T>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base,
+                                              int fr, int fq) {
+    // wave-uniform: the wave's whole FM*16 x FN*16 patch lies inside the matrix
+    const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
+    if (interior) gemm_epilogue_impl<T, true>(p, acc, m_base, n_base, fr, fq);
+    else gemm_epilogue_impl<T, false>(p, acc, m_base, n_base, fr, fq);
+}
+
 // XCD-aware, bijective block -> tile map: blocks that share an XCD (id % 8) get a contiguous run of
 // tiles, n fastest, so neighbours re-use the same A rows out of that XCD's L2.
 __device__ __forceinline__ int xcd_tile(int orig, int nwg) {
     const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+}
+
+// Linear tile index -> (tm, tn): column panels GROUP_N tiles wide, row-major inside a panel.  The
+// ~64 tiles an XCD runs concurrently (a contiguous run of the index, xcd_tile) then form an
+// ~8 x 8 block: 8 A row-tiles + 8 W col-tiles (~3.5 MB at K = 768) fit its 4 MiB L2, where the plain
+// n-fastest order swept all of W per row-tile and overflowed it (21 % L2 misses, 4.7x over-fetch).
+constexpr int GEMM_GROUP_N = 8;
+__device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int panel = tile / (GEMM_GROUP_N * tiles_m);
+    const int within = tile - panel * GEMM_GROUP_N * tiles_m;
+    const int width = min(GEMM_GROUP_N, tiles_n - panel * GEMM_GROUP_N);
+    tm = within / width;
+    tn = panel * GEMM_GROUP_N + (within - tm * width);
 }
 
 template <class T>
@@ -141,10 +186,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave / T::WAVES_N, wc = wave % T::WAVES_N;
 
-    const int tiles_n = ceil_div(p.N, T::BN);
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * T::BM;
-    const int n0 = (tile % tiles_n) * T::BN;
+    int tm, tn;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
+    const int m0 = tm * T::BM;
+    const int n0 = tn * T::BN;
 
     f32x4 acc[T::FM][T::FN];
 #pragma unroll

@@ -26,7 +26,7 @@ struct GemmParams {
     int debug;                      // microbenchmark ablations only (0 in the product): 1 = no DMA in the K loop, 2 = no MFMA
 };
 
-enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_VARIANTS = 4 };
+enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_VARIANTS = 6 };
 // Operand allocations must be readable up to the tile edge: A rows up to round_up(M,256)+256,
 // W rows up to round_up(N,256) (engine.hip pads every buffer accordingly).
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);                       // picks the tile

@@ -1,5 +1,5 @@
 // Instantiations of the bf16 MFMA GEMM template (gemm_kernel.h) and the per-shape tile choice.
-#include "gemm256_kernel.h"
+#include "gemm256ps_kernel.h"
 #include <cmath>
 
 namespace ivit {
@@ -25,6 +25,14 @@ __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x6
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm256_body<0>(p, smem);
 }
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256s_body<0>(p, smem);
+}
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_persist(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256ps_body(p, smem);
+}
 #ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): timing ablations, wrong results
 __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_256pipe_nodma(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -34,6 +42,14 @@ __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_256pipe_nomfma
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm256_body<2>(p, smem);
 }
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_256stag_nodma(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256s_body<1>(p, smem);
+}
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_256stag_nomfma(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256s_body<2>(p, smem);
+}
 #endif
 
 const char* gemm_variant_name(int v) {
@@ -42,6 +58,8 @@ const char* gemm_variant_name(int v) {
         case GEMM_TILE_160: return "ivit_gemm_bf16_160x128x64";
         case GEMM_TILE_256: return "ivit_gemm_bf16_256x256x64";
         case GEMM_TILE_256P: return "ivit_gemm_bf16_256x256x64_pipe";
+        case GEMM_TILE_256S: return "ivit_gemm_bf16_256x256x64_stag";
+        case GEMM_TILE_256PS: return "ivit_gemm_bf16_256x256x64_persist";
     }
     return "?";
 }
@@ -86,6 +104,31 @@ int gemm_pick_variant(int M, int N, int K) {
     return best;
 }
 
+static int device_cu_count() {
+    static int cus = 0;   // one process drives one GPU
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// persistent kernel: one workgroup per CU (or per tile when there are fewer tiles than CUs)
+static hipError_t launch_persistent(const GemmParams& p, hipStream_t stream) {
+    using T = Tile256P;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_gemm_bf16_256x256x64_persist),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = ceil_div(p.M, T::BM) * ceil_div(p.N, T::BN);
+    const int grid = tiles < device_cu_count() ? tiles : device_cu_count();
+    hipLaunchKernelGGL(ivit_gemm_bf16_256x256x64_persist, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (p.K <= 0 || p.K % GEMM_BK != 0) return hipErrorInvalidValue;
@@ -101,6 +144,15 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
             if (p.debug == 2) return launch_tile<Tile256P>(ivit_gemm_256pipe_nomfma, p, stream);
 #endif
             return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_pipe, p, stream);
+        case GEMM_TILE_256S:
+#ifdef IVIT_GEMM_ABLATIONS
+            if (p.debug == 1) return launch_tile<Tile256P>(ivit_gemm_256stag_nodma, p, stream);
+            if (p.debug == 2) return launch_tile<Tile256P>(ivit_gemm_256stag_nomfma, p, stream);
+#endif
+            return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag, p, stream);
+        case GEMM_TILE_256PS:
+            if (p.K < 2 * GEMM_BK) return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag, p, stream);
+            return launch_persistent(p, stream);
     }
     return hipErrorInvalidValue;
 }
