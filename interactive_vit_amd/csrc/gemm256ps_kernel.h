@@ -8,8 +8,8 @@
 // "SR1: B1(g+1), SR2: A1(g+1), SR3: A0(g+2), SR4: B0(g+2)" simply run on across the tile boundary,
 // so the first K-tiles of output tile i+1 are loading while tile i finishes and while its epilogue
 // stores drain.  The epilogue (bias / GELU / residual / remap, shared with the other GEMM kernels)
-// runs between the last M4 of a tile and the first SR1 of the next; it holds no barrier, so the two
-// wave groups keep their one-interval stagger.  s_waitcnt vmcnt(8) stays valid with epilogue stores
+// runs between the last M4 of a tile and the first SR1 of the next; the two wave groups are brought
+// level for it and re-staggered afterwards (one extra barrier each per tile).  s_waitcnt vmcnt(8) stays valid with epilogue stores
 // in the queue (vmcnt counts stores too): it is then merely conservative.
 // LDS buffer sets alternate with the running K-tile counter g (not the tile-local index), so an odd
 // K-tile count per output tile is fine.  Requires K >= 128 (two K-tiles).
@@ -154,11 +154,15 @@ __device__ __forceinline__ void gemm256ps_body(const GemmParams& p, char* smem) 
     IVIT_VMCNT(8);
     __builtin_amdgcn_s_barrier();
     const bool late = wave >= 4;     // waves 4-7 run one barrier interval behind waves 0-3
-    if (late) __builtin_amdgcn_s_barrier();
 
     bf16x8 a[4][2], b0[2][2], b1[2][2];
     int g = 0;
     for (; tile < num_tiles; tile += G) {
+        // (re-)establish the stagger: the late group's extra barrier pairs with the early group's
+        // end-of-SR1 barrier; at the end of the tile the early group waits one interval so that both
+        // groups run their epilogues CONCURRENTLY (left staggered, the barriers serialise them: the
+        // late group cannot leave its last M4 before the early group has finished its epilogue)
+        if (late) __builtin_amdgcn_s_barrier();
         const int next = tile + G;
         if (next < num_tiles) {
             g256p_tile_src(p, next, tiles_m, tiles_n, wave, lane, c.a_nxt, c.w_nxt, m0n, n0n);
@@ -166,6 +170,7 @@ __device__ __forceinline__ void gemm256ps_body(const GemmParams& p, char* smem) 
             c.a_nxt = c.a_cur; c.w_nxt = c.w_cur;
         }
         for (int t = 0; t < c.nt; ++t, ++g) g256p_ktile(c, t, g, acc, a, b0, b1);
+        if (!late) __builtin_amdgcn_s_barrier();
 
         gemm_epilogue<T>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq);
 #pragma unroll
@@ -174,7 +179,6 @@ __device__ __forceinline__ void gemm256ps_body(const GemmParams& p, char* smem) 
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         c.a_cur = c.a_nxt; c.w_cur = c.w_nxt; m0 = m0n; n0 = n0n;
     }
-    if (!late) __builtin_amdgcn_s_barrier();
     IVIT_VMCNT(0);   // the last run-ahead stagings may still be writing LDS
 }
 

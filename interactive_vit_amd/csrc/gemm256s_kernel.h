@@ -74,9 +74,23 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
     __builtin_amdgcn_s_barrier();
 }
 
+#ifdef IVIT_GEMM_ABLATIONS
+#define IVIT_STAMP(slot)                                                                                      \
+    do {                                                                                                      \
+        if (p.stamps && (threadIdx.x & 255) == 0) {                                                           \
+            unsigned long long t_;                                                                            \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+            p.stamps[((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 8 + (slot)] = t_;                        \
+        }                                                                                                     \
+    } while (0)
+#else
+#define IVIT_STAMP(slot) do { } while (0)
+#endif
+
 template <int DBG>
 __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     using T = Tile256P;
+    IVIT_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -119,6 +133,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     g256_stage<true>(c, k1, 1, 0);
     IVIT_VMCNT(8);   // A0(0), B0(0) landed; 4 half-tiles in flight
     __builtin_amdgcn_s_barrier();
+    IVIT_STAMP(1);
     // waves 4-7 start one barrier interval late; waves 0-3 make it up after the loop
     const bool late = wave >= 4;
     if (late) __builtin_amdgcn_s_barrier();
@@ -127,8 +142,11 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     for (int t = 0; t < nt; ++t) g256s_ktile<DBG>(c, t, last_kt, acc, a, b0, b1);
 
     if (!late) __builtin_amdgcn_s_barrier();
+    IVIT_STAMP(2);
     gemm_epilogue<T>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq);
+    IVIT_STAMP(3);
     IVIT_VMCNT(0);   // the clamped tail stagings may still be writing LDS
+    IVIT_STAMP(4);
 }
 
 }  // namespace ivit

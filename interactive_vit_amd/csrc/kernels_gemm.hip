@@ -77,17 +77,19 @@ static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream)
     return hipGetLastError();
 }
 
-// Tile choice, from tools/gemm_bench on MI355X (ViT-B/16 shapes, M = 12608; TFLOP/s):
-//                       128x128   160x128   256x256   256x256_pipe
-//   N=2304 K= 768 (qkv)   643       640       614        620
-//   N= 768 K= 768 (proj)  363       462       333        326
-//   N=3072 K= 768 (mlp1)  498       512       450        386      (with the GELU epilogue)
-//   N= 768 K=3072 (mlp2)  671       885       645        644
-// The two-workgroups-per-CU tiles overlap one tile's epilogue with the other's main loop; the
-// 256x256 tiles (one workgroup per CU, lockstep rounds) pay their output burst serially and lose
-// despite half the L2->LDS traffic.  So: 160x128 unless the 128x128 grid fills the 512 slots better.
+// Tile choice, from tools/gemm_bench on MI355X (ViT-B/16 shapes, M = 12608; TFLOP/s, batched epilogue):
+//                       128x128   160x128   256x256 staggered   256x256 persistent
+//   N=2304 K= 768 (qkv)   ~640       717          758                 745
+//   N= 768 K= 768 (proj)  ~370       528          435                 402
+//   N=3072 K= 768 (mlp1)  ~600       726          686                 671      (with the GELU epilogue)
+//   N= 768 K=3072 (mlp2)  ~660       912          809                 744
+// Both families sit on the same wall: the per-CU L2->LDS path delivers ~55-60 GB/s, which caps a
+// 160x128 tile (71 FLOP/B) near 1000 TFLOP/s; the 256x256 tile (128 FLOP/B) has the headroom but one
+// workgroup per CU, so its epilogue (13 us for an f32 residual tile, in-kernel stamps) is not hidden
+// by another workgroup's main loop and its grid quantises worse.  It wins only on wide, bf16-output
+// shapes with >= 2 rounds of tiles.
 int gemm_pick_variant(int M, int N, int K) {
-    (void)K;
+    if (N >= 2048 && N <= 2560 && K <= 1024 && M >= 8192) return GEMM_TILE_256S;   // QKV-like
     struct Cand { int v, bm, bn; double speed; };
     static const Cand cands[] = {
         {GEMM_TILE_160, Tile160::BM, Tile160::BN, 1.03},

@@ -54,6 +54,10 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(db, hb.data(), maxN * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dres, 0, (size_t)maxM * maxN * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int stamp_variant = argc > 6 ? atoi(argv[6]) : -1;   // variant whose blocks are time-stamped
+    unsigned long long* dstamps = nullptr;
+    const int max_blocks = 4096;
+    CK(hipMalloc(&dstamps, (size_t)max_blocks * 16 * 8));
 
     int shape_idx = -1;
     for (const Shape& s : shapes) {
@@ -97,6 +101,37 @@ int main(int argc, char** argv) {
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 times[v].push_back(ms / iters);
             }
+        if (stamp_variant >= 0) {
+            CK(hipMemset(dstamps, 0, (size_t)max_blocks * 16 * 8));
+            GemmParams q = p; q.stamps = dstamps;
+            for (int i = 0; i < 3; ++i) CK(launch_gemm_variant(p, stamp_variant, 0));   // warm
+            CK(hipDeviceSynchronize());
+            CK(launch_gemm_variant(q, stamp_variant, 0));
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> hs((size_t)max_blocks * 16);
+            CK(hipMemcpy(hs.data(), dstamps, hs.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long tmin = ~0ull; int nb = 0;
+            for (int b = 0; b < max_blocks; ++b) if (hs[(size_t)b * 16]) { tmin = std::min(tmin, hs[(size_t)b * 16]); nb = b + 1; }
+            double seg[2][5] = {{0}}, startsum = 0, endmax = 0; int cnt = 0;
+            for (int b = 0; b < nb; ++b) {
+                if (!hs[(size_t)b * 16]) continue;
+                ++cnt;
+                for (int g = 0; g < 2; ++g) {
+                    const unsigned long long* t = &hs[((size_t)b * 2 + g) * 8];
+                    for (int k = 1; k < 5; ++k) seg[g][k] += (double)(t[k] - t[k - 1]) * 0.01;   // 100 MHz -> us
+                }
+                startsum += (double)(hs[(size_t)b * 16] - tmin) * 0.01;
+                endmax = std::max(endmax, (double)(hs[(size_t)b * 16 + 4] - tmin) * 0.01);
+            }
+            printf("   stamps %s: %d blocks; mean start offset %.2f us, last end %.2f us\n", gemm_variant_name(stamp_variant), cnt, startsum / cnt, endmax);
+            for (int g = 0; g < 2; ++g)
+                printf("      group %d: prologue %.2f us | K loop %.2f us | epilogue issue %.2f us | drain %.2f us\n", g,
+                       seg[g][1] / cnt, seg[g][2] / cnt, seg[g][3] / cnt, seg[g][4] / cnt);
+            // histogram of block start times (rounds)
+            int late_blocks = 0;
+            for (int b = 0; b < nb; ++b) if (hs[(size_t)b * 16] && (double)(hs[(size_t)b * 16] - tmin) * 0.01 > 5.0) ++late_blocks;
+            printf("      blocks starting > 5 us after the first: %d\n", late_blocks);
+        }
         for (int v = 0; v < GEMM_VARIANTS; ++v) {
             if (!((vmask >> v) & 1)) continue;
             std::sort(times[v].begin(), times[v].end());
