@@ -182,8 +182,25 @@ def main():
         g = classes["gemm"]
         avg_us = g["ms"] * 1e3 / max(1, g["launches"])
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "ivit_gemm_bf16_160x128x64", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        # HBM bytes per GEMM launch from the PMC passes of tools/pmc_bench.sh (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md);
+        # bench.py cannot drive the profiler from inside, so it carries the committed summary or null
+        traffic = None
+        try:
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]
+            ks = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
+            tot = n = 0.0
+            for name, rec in ks.items():
+                if "gemm" in name and rec.get("hbm_bytes_per_launch"):
+                    tot += rec["hbm_bytes_per_launch"] * rec["launches_profiled"]
+                    n += rec["launches_profiled"]
+            if n:
+                traffic = {"hbm_bytes_per_launch": round(tot / n), "source": f"profiles/{prof}"}
+        except Exception:
+            traffic = None
+        roofline = {"bound": "mfma", "kernel": "ivit_gemm_bf16_160x128x64 (+ ivit_gemm_bf16_256x256x64_stag for QKV)",
+                    "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches_per_step": g["launches"] // args.steps, "avg_launch_us": round(avg_us, 2),
                     "algorithmic_gflop_per_step": round(g["flops"] / args.steps / 1e9, 2),
                     "measured": "HIP events on the launch stream around every launch, separate instrumented pass of the same K steps",
