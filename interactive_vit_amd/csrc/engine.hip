@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -100,11 +101,23 @@ struct LayerWeights {
     Matrix w_in, w_out, w1, w2;
 };
 
+// Row-offset view of the activation workspaces: the whole batch, or one of the sub-batches that
+// run concurrently on separate streams (every row of every buffer belongs to exactly one image).
+struct Ws {
+    bf16_t *patches, *h, *qkv, *att, *u, *hc;
+    float *x, *clsf;
+};
+
 struct ivit_engine {
     ivit_config cfg{};
     int G = 0, Np = 0, N = 0, K = 0, Kp = 0, D = 0, dh = 0;
     std::mutex mu;
     hipStream_t own_stream = nullptr;
+    // sub-batch concurrency: memory-bound kernels (LayerNorm, attention staging, GEMM epilogues) of
+    // one half of the batch overlap the MFMA-bound main loops of the other half
+    int split = 1, split_min_batch = 16;
+    hipStream_t aux_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::vector<void*> allocs;
     std::map<std::string, bool> have;
     bool weights_complete = false;
@@ -191,6 +204,19 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     auto chk = [&](int r) { rc |= r; };
 
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); }
+    {
+        // IVIT_SPLIT=2 runs the two halves of a batch on two streams.  Measured on MI355X (ViT-B/16,
+        // B=64): kernels overlap (their durations double) but images/s does not move (19.0k vs 18.9k) -
+        // all kernels queue on the same per-CU vector-memory path - so it is off by default.
+        const char* sp = getenv("IVIT_SPLIT");
+        e->split = sp ? atoi(sp) : 1;
+        if (e->split < 1 || e->split > 2) e->split = 1;
+        for (int i = 0; i < 2; ++i) {
+            if (hipStreamCreateWithFlags(&e->aux_stream[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("aux stream/event creation failed"); }
+        }
+        if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("event creation failed"); }
+    }
     chk(alloc_matrix(e, &e->w_patch, D, e->K));
     chk(alloc_vec(e, &e->b_patch, D));
     chk(alloc_vec(e, &e->cls_tok, D));
@@ -241,6 +267,11 @@ extern "C" void ivit_destroy(ivit_engine* e) {
     for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
+        if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     delete e;
 }
 
@@ -356,24 +387,24 @@ static int run_layernorm(ivit_engine* e, hipStream_t st, const float* x, int64_t
     return 0;
 }
 
-static int run_layer(ivit_engine* e, hipStream_t st, int li, int B) {
+static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B) {
     const int D = e->D, M = B * e->N, Mlp = e->cfg.mlp;
     LayerWeights& lw = e->layers[li];
-    if (run_layernorm(e, st, e->x, 1, M, lw.ln1_g, lw.ln1_b, e->h, nullptr)) return 1;
-    if (run_gemm(e, st, e->h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, e->qkv, 3 * D)) return 1;
+    if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
+    if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
     {
         AttnParams ap{};
-        ap.qkv = e->qkv; ap.ldqkv = 3 * D; ap.out = e->att; ap.ldo = D;
+        ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = D;
         ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh;
         ap.scale = 1.0f / std::sqrt((float)e->dh);
         const double flops = 4.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh;
         ProfScope ps(e, PC_ATTN, st, flops, 2.0 * M * 4.0 * D);
         HIP_TRY(launch_attention(ap, st));
     }
-    if (run_gemm(e, st, e->att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, e->x, D, e->x, D)) return 1;
-    if (run_layernorm(e, st, e->x, 1, M, lw.ln2_g, lw.ln2_b, e->h, nullptr)) return 1;
-    if (run_gemm(e, st, e->h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, e->u, Mlp)) return 1;
-    if (run_gemm(e, st, e->u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, e->x, D, e->x, D)) return 1;
+    if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
+    if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, w.h, nullptr)) return 1;
+    if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp)) return 1;
+    if (run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
     return 0;
 }
 
@@ -386,12 +417,10 @@ static int check_range(ivit_engine* e, int begin, int end, int batch) {
 }
 
 // caller holds e->mu and has set the device
-static int forward_locked(ivit_engine* e, int begin, int end, int B, const float* in, float* out, float* cls_out,
-                          hipStream_t st) {
+static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, const float* in, float* out, float* cls_out,
+                       hipStream_t st) {
     const int L = e->cfg.layers, D = e->D, N = e->N, Np = e->Np;
     const int ST_LN = ST_LAYER0 + L, ST_CLS = ST_LN + 1, ST_HEADS = ST_LN + 2;
-    if (require_weights(e)) return 1;
-
     const float* cur = in;
     bool in_x = false, patches_ready = false;
     int s = begin;
@@ -404,7 +433,7 @@ static int forward_locked(ivit_engine* e, int begin, int end, int B, const float
         }
         {
             ProfScope ps(e, PC_OTHER, st, 0.0, 4.0 * B * 3 * e->cfg.image * e->cfg.image + 2.0 * B * Np * e->Kp);
-            HIP_TRY(launch_unfold(cur, e->patches, B, e->cfg.image, e->cfg.patch, e->Kp, 1, st));
+            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 1, st));
         }
         patches_ready = true;
         s = ST_CONV;
@@ -412,24 +441,24 @@ static int forward_locked(ivit_engine* e, int begin, int end, int B, const float
     if (s == ST_CONV) {
         if (!patches_ready) {
             ProfScope ps(e, PC_OTHER, st, 0.0, 4.0 * B * 3 * e->cfg.image * e->cfg.image + 2.0 * B * Np * e->Kp);
-            HIP_TRY(launch_unfold(cur, e->patches, B, e->cfg.image, e->cfg.patch, e->Kp, 0, st));
+            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 0, st));
         }
         if (end == ST_CONV + 1)
-            return run_gemm(e, st, e->patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_F32, out, D);
+            return run_gemm(e, st, w.patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_F32, out, D);
         // conv_proj + tokens fused: the GEMM epilogue scatters rows to token 1+n of each image and adds
         // the position embedding; a small kernel writes the class rows
-        if (run_gemm(e, st, e->patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_ROWADD_F32,
-                     (end == ST_TOKENS + 1) ? out : e->x, D, nullptr, 0, e->pos, D, Np, N, 1)) return 1;
+        if (run_gemm(e, st, w.patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_ROWADD_F32,
+                     (end == ST_TOKENS + 1) ? out : w.x, D, nullptr, 0, e->pos, D, Np, N, 1)) return 1;
         {
             ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * D);
-            HIP_TRY(launch_tokens(nullptr, e->cls_tok, e->pos, (end == ST_TOKENS + 1) ? out : e->x, B, Np, D, st));
+            HIP_TRY(launch_tokens(nullptr, e->cls_tok, e->pos, (end == ST_TOKENS + 1) ? out : w.x, B, Np, D, st));
         }
         if (end == ST_TOKENS + 1) return 0;
         in_x = true;
         s = ST_LAYER0;
     }
     if (s == ST_TOKENS) {
-        float* dst = (end == ST_TOKENS + 1) ? out : e->x;
+        float* dst = (end == ST_TOKENS + 1) ? out : w.x;
         {
             ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * N * D);
             HIP_TRY(launch_tokens(cur, e->cls_tok, e->pos, dst, B, Np, D, st));
@@ -440,29 +469,29 @@ static int forward_locked(ivit_engine* e, int begin, int end, int B, const float
     }
     for (; s < end && s < ST_LN; ++s) {
         if (!in_x) {
-            HIP_TRY(hipMemcpyAsync(e->x, cur, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(w.x, cur, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
             in_x = true;
         }
-        if (run_layer(e, st, s - ST_LAYER0, B)) return 1;
+        if (run_layer(e, w, st, s - ST_LAYER0, B)) return 1;
     }
     if (s >= end) {   // the range ended on an encoder layer: hand the residual stream out
-        HIP_TRY(hipMemcpyAsync(out, e->x, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(out, w.x, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
         return 0;
     }
     if (s == ST_LN) {
-        const float* src = in_x ? e->x : cur;
+        const float* src = in_x ? w.x : cur;
         if (end == ST_LN + 1) return run_layernorm(e, st, src, 1, B * N, e->lnf_g, e->lnf_b, nullptr, out);
         // only the class rows are consumed downstream: normalise B rows (stride N)
-        float* feat = (end == ST_CLS + 1) ? out : (cls_out ? cls_out : e->clsf);
-        if (run_layernorm(e, st, src, N, B, e->lnf_g, e->lnf_b, e->hc, feat)) return 1;
+        float* feat = (end == ST_CLS + 1) ? out : (cls_out ? cls_out : w.clsf);
+        if (run_layernorm(e, st, src, N, B, e->lnf_g, e->lnf_b, w.hc, feat)) return 1;
         if (end == ST_CLS + 1) {
             if (cls_out) HIP_TRY(hipMemcpyAsync(cls_out, out, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
             return 0;
         }
-        return run_gemm(e, st, e->hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes);
+        return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes);
     }
     if (s == ST_CLS) {
-        float* dst = (end == ST_CLS + 1) ? out : e->clsf;
+        float* dst = (end == ST_CLS + 1) ? out : w.clsf;
         {
             ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * D);
             HIP_TRY(launch_gather_rows(cur, N, dst, B, D, st));
@@ -475,9 +504,46 @@ static int forward_locked(ivit_engine* e, int begin, int end, int B, const float
     // heads on an f32 [B,D] input
     {
         ProfScope ps(e, PC_OTHER, st, 0.0, 6.0 * B * D);
-        HIP_TRY(launch_f32_to_bf16(cur, D, e->hc, D, B, D, st));
+        HIP_TRY(launch_f32_to_bf16(cur, D, w.hc, D, B, D, st));
     }
-    return run_gemm(e, st, e->hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes);
+    return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes);
+}
+
+static Ws ws_slice(ivit_engine* e, int b0) {
+    const size_t rt = (size_t)b0 * e->N, rp = (size_t)b0 * e->Np;
+    Ws w;
+    w.patches = e->patches + rp * e->Kp;
+    w.x = e->x + rt * e->D;
+    w.h = e->h + rt * e->D;
+    w.qkv = e->qkv + rt * 3 * e->D;
+    w.att = e->att + rt * e->D;
+    w.u = e->u + rt * e->cfg.mlp;
+    w.hc = e->hc + (size_t)b0 * e->D;
+    w.clsf = e->clsf + (size_t)b0 * e->D;
+    return w;
+}
+
+// caller holds e->mu and has set the device
+static int forward_locked(ivit_engine* e, int begin, int end, int B, const float* in, float* out, float* cls_out,
+                          hipStream_t st) {
+    if (require_weights(e)) return 1;
+    const int L = e->cfg.layers;
+    const bool has_layers = (begin < ST_LAYER0 + L) && (end > ST_LAYER0);
+    if (e->split < 2 || B < e->split_min_batch || !has_layers) return forward_one(e, ws_slice(e, 0), begin, end, B, in, out, cls_out, st);
+    // fork: two sub-batches on two streams; join back into the caller's stream
+    const int64_t n_in = shape_elems(&e->cfg, begin, 0), n_out = shape_elems(&e->cfg, end - 1, 1);
+    HIP_TRY(hipEventRecord(e->ev_fork, st));
+    const int half = (B + 1) / 2;
+    for (int i = 0; i < 2; ++i) {
+        const int b0 = i * half, bn = (i == 0) ? half : B - half;
+        hipStream_t s = e->aux_stream[i];
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_fork, 0));
+        if (forward_one(e, ws_slice(e, b0), begin, end, bn, in + (size_t)b0 * n_in, out + (size_t)b0 * n_out,
+                        cls_out ? cls_out + (size_t)b0 * e->D : nullptr, s)) return 1;
+        HIP_TRY(hipEventRecord(e->ev_join[i], s));
+    }
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(st, e->ev_join[i], 0));
+    return 0;
 }
 
 extern "C" int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_end, int batch, const void* in, void* out,

@@ -18,8 +18,7 @@
 // 128-B rows) and is transposed on the fly by ds_read_b64_tr_b16: per 16-lane group the instruction
 // reads a 4-key x 16-d block and hands lane i the 4 keys of column d0 + i - exactly the V^T fragment
 // half (keys 32 s + 4 g .. +3, then +16).  V's 16-B chunks are XOR-swizzled by ((key >> 1) & 3) << 1,
-// which makes those reads bank-conflict free.  K and V fragments are shared by the wave's QB query
-// blocks.  Softmax statistics are fp32; row max / sum are wavefront shuffles across the 4 lane groups.
+// which makes those reads bank-conflict free.  Softmax statistics are fp32; row max / sum are wavefront shuffles across the 4 lane groups.
 #include "kernels.h"
 
 namespace ivit {
@@ -75,47 +74,47 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     const int q0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * L::QPW;
     if (q0 >= N) return;  // whole wave idle (after the only barrier)
 
-    // ---- Q fragments (B operand): lane holds Q[q0 + 16c + fr][kk*32 + 8g .. +7]
-    bf16x8 qf[QB][2];
-#pragma unroll
-    for (int c = 0; c < QB; ++c) {
-        const int qrow = min(q0 + c * 16 + fr, N - 1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            qf[c][kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8);
-    }
-
-    // ---- S^T = K Q^T
-    f32x4 s[QB][NKF];
-#pragma unroll
-    for (int f = 0; f < NKF; ++f) {
-        const int key = f * 16 + fr;
-        bf16x8 kf[2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            kf[kk] = *reinterpret_cast<const bf16x8*>(k_lds + key * 128 + (((kk * 4 + g) ^ (key & 7)) << 4));
-#pragma unroll
-        for (int c = 0; c < QB; ++c) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[c][0], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[c][1], a, 0, 0, 0);
-            s[c][f] = a;
-        }
-    }
-
-    // ---- softmax over keys; only the last two fragments can hold padded keys (KEYS - N < 32)
+    // transposed-read addressing: lane i = 4q + p of its 16-lane group supplies &V[key0 + q][d0 + 4p]
+    const int tq = fr >> 2, tp = fr & 3;
     const float cexp = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*scale*log2 e)
-    float inv[QB];
-#pragma unroll
+
+    // The wave's QB 16-query blocks run one after the other, so only one block's scores (NKF x 4
+    // registers) are live at a time: < 128 VGPRs at 197 keys, i.e. two 7-wave workgroups per CU and
+    // one's staging overlaps the other's math.  (K / V fragments are re-read per block: LDS has room.)
+#pragma unroll 1
     for (int c = 0; c < QB; ++c) {
+        const int qbase = q0 + c * 16;
+        if (qbase >= N) break;   // wave-uniform
+        // ---- Q fragments (B operand): lane holds Q[qbase + fr][kk*32 + 8g .. +7]
+        const int qrow = min(qbase + fr, N - 1);
+        bf16x8 qf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8);
+
+        // ---- S^T = K Q^T
+        f32x4 s[NKF];
+#pragma unroll
+        for (int f = 0; f < NKF; ++f) {
+            const int key = f * 16 + fr;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + key * 128 + (((kk * 4 + g) ^ (key & 7)) << 4));
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], a, 0, 0, 0);
+            }
+            s[f] = a;
+        }
+
+        // ---- softmax over keys; only the last two fragments can hold padded keys (KEYS - N < 32)
 #pragma unroll
         for (int f = NKF - 2; f < NKF; ++f)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (f * 16 + g * 4 + j >= N) s[c][f][j] = -INFINITY;
+                if (f * 16 + g * 4 + j >= N) s[f][j] = -INFINITY;
         float mx = -INFINITY;
 #pragma unroll
-        for (int f = 0; f < NKF; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[c][f][0], s[c][f][1]), fmaxf(s[c][f][2], s[c][f][3])));
+        for (int f = 0; f < NKF; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[f][0], s[f][1]), fmaxf(s[f][2], s[f][3])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mc = mx * cexp;
@@ -124,62 +123,50 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
         for (int f = 0; f < NKF; ++f)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[c][f][j], cexp, -mc));
-                s[c][f][j] = e;
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[f][j], cexp, -mc));
+                s[f][j] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        inv[c] = 1.0f / sum;
-    }
+        const float inv = 1.0f / sum;
 
-    // ---- O^T = V^T P^T
-    f32x4 o[QB][4];
+        // ---- O^T = V^T P^T
+        f32x4 o[4];
 #pragma unroll
-    for (int c = 0; c < QB; ++c)
+        for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int d = 0; d < 4; ++d) o[c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // transposed-read addressing: lane i = 4q + p of its 16-lane group supplies &V[key0 + q][d0 + 4p]
-    const int tq = fr >> 2, tp = fr & 3;
-#pragma unroll
-    for (int st = 0; st < NKF / 2; ++st) {
-        bf16x8 pf[QB];
-#pragma unroll
-        for (int c = 0; c < QB; ++c) {
-            const f32x4 p0 = s[c][2 * st], p1 = s[c][2 * st + 1];
+        for (int st = 0; st < NKF / 2; ++st) {
+            const f32x4 p0 = s[2 * st], p1 = s[2 * st + 1];
             union { bf16x8 v; unsigned int u[4]; } pk;
             pk.u[0] = pack_bf16x2(p0[0], p0[1]);
             pk.u[1] = pack_bf16x2(p0[2], p0[3]);
             pk.u[2] = pack_bf16x2(p1[0], p1[1]);
             pk.u[3] = pack_bf16x2(p1[2], p1[3]);
-            pf[c] = pk.v;
-        }
-        const int key_lo = 32 * st + 4 * g + tq;       // first half of the k-slots; second half = +16 keys
-        const int sw_lo = ((key_lo >> 1) & 3) << 1, sw_hi = (((key_lo + 16) >> 1) & 3) << 1;
+            const int key_lo = 32 * st + 4 * g + tq;       // first half of the k-slots; second half = +16 keys
+            const int sw_lo = ((key_lo >> 1) & 3) << 1, sw_hi = (((key_lo + 16) >> 1) & 3) << 1;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int chunk = d * 2 + (tp >> 1);       // 16-B chunk of columns d*16 + 4*tp
-            const char* lo = v_lds + key_lo * 128 + ((chunk ^ sw_lo) << 4) + (tp & 1) * 8;
-            const char* hi = v_lds + (key_lo + 16) * 128 + ((chunk ^ sw_hi) << 4) + (tp & 1) * 8;
-            union { bf16x8 v; bf16x4 h2[2]; } vf;
-            vf.h2[0] = lds_read_tr16(lo);
-            vf.h2[1] = lds_read_tr16(hi);
-#pragma unroll
-            for (int c = 0; c < QB; ++c) o[c][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[c], o[c][d], 0, 0, 0);
+            for (int d = 0; d < 4; ++d) {
+                const int chunk = d * 2 + (tp >> 1);       // 16-B chunk of columns d*16 + 4*tp
+                const char* lo = v_lds + key_lo * 128 + ((chunk ^ sw_lo) << 4) + (tp & 1) * 8;
+                const char* hi = v_lds + (key_lo + 16) * 128 + ((chunk ^ sw_hi) << 4) + (tp & 1) * 8;
+                union { bf16x8 v; bf16x4 h2[2]; } vf;
+                vf.h2[0] = lds_read_tr16(lo);
+                vf.h2[1] = lds_read_tr16(hi);
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, o[d], 0, 0, 0);
+            }
         }
-    }
 
-    // ---- normalise and store: lane holds O[q0 + 16c + fr][16 d + 4 g .. +3]
-#pragma unroll
-    for (int c = 0; c < QB; ++c) {
-        const int q = q0 + c * 16 + fr;
+        // ---- normalise and store: lane holds O[qbase + fr][16 d + 4 g .. +3]
+        // (the guard diverges only here, after the last transposed read of this block, which needs
+        // EXEC all ones; the next block's reads run with the full mask again)
+        const int q = qbase + fr;
         if (q < N) {
             bf16_t* orow = p.out + (row0 + q) * p.ldo + h * ATT_DH + g * 4;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                u32x2 pk = {pack_bf16x2(o[c][d][0] * inv[c], o[c][d][1] * inv[c]),
-                            pack_bf16x2(o[c][d][2] * inv[c], o[c][d][3] * inv[c])};
-                *reinterpret_cast<u32x2*>(orow + d * 16) = pk;
+                u32x2 pk2 = {pack_bf16x2(o[d][0] * inv, o[d][1] * inv), pack_bf16x2(o[d][2] * inv, o[d][3] * inv)};
+                *reinterpret_cast<u32x2*>(orow + d * 16) = pk2;
             }
         }
     }

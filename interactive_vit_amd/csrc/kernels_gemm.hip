@@ -6,7 +6,7 @@ namespace ivit {
 
 using Tile128 = GemmTile<2, 2, 4, 4>;   // 128 x 128, 4 waves (64x64 each), 64 KiB LDS, 2 blocks/CU
 using Tile160 = GemmTile<2, 2, 5, 4>;   // 160 x 128, 4 waves (80x64 each), 72 KiB LDS, 2 blocks/CU
-using Tile256 = GemmTile<2, 4, 8, 4>;   // 256 x 256, 8 waves (128x64 each), 128 KiB LDS, 1 block/CU
+using Tile256 = GemmTile<2, 4, 8, 4>;   // 256 x 256, 8 waves, plain double buffer (microbenchmark baseline only)
 
 __global__ __launch_bounds__(Tile128::THREADS, 2) void ivit_gemm_bf16_128x128x64(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -16,24 +16,24 @@ __global__ __launch_bounds__(Tile160::THREADS, 2) void ivit_gemm_bf16_160x128x64
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_body<Tile160>(p, smem);
 }
+
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256s_body<0>(p, smem);
+}
+#ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost, and timing ablations
 __global__ __launch_bounds__(Tile256::THREADS, 2) void ivit_gemm_bf16_256x256x64(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_body<Tile256>(p, smem);
 }
-
 __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_pipe(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm256_body<0>(p, smem);
-}
-__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm256s_body<0>(p, smem);
 }
 __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_persist(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm256ps_body(p, smem);
 }
-#ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): timing ablations, wrong results
 __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_256pipe_nodma(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm256_body<1>(p, smem);
@@ -89,7 +89,7 @@ static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream)
 // by another workgroup's main loop and its grid quantises worse.  It wins only on wide, bf16-output
 // shapes with >= 2 rounds of tiles.
 int gemm_pick_variant(int M, int N, int K) {
-    if (N >= 2048 && N <= 2560 && K <= 1024 && M >= 8192) return GEMM_TILE_256S;   // QKV-like
+    if (N >= 2048 && N <= 2560 && K <= 1024 && M >= 4096) return GEMM_TILE_256S;   // QKV-like
     struct Cand { int v, bm, bn; double speed; };
     static const Cand cands[] = {
         {GEMM_TILE_160, Tile160::BM, Tile160::BN, 1.03},
@@ -115,6 +115,7 @@ static int device_cu_count() {
     return cus;
 }
 
+#ifdef IVIT_GEMM_ABLATIONS
 // persistent kernel: one workgroup per CU (or per tile when there are fewer tiles than CUs)
 static hipError_t launch_persistent(const GemmParams& p, hipStream_t stream) {
     using T = Tile256P;
@@ -130,6 +131,7 @@ static hipError_t launch_persistent(const GemmParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(ivit_gemm_bf16_256x256x64_persist, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, p);
     return hipGetLastError();
 }
+#endif
 
 hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
@@ -139,22 +141,22 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
     switch (variant) {
         case GEMM_TILE_128: return launch_tile<Tile128>(ivit_gemm_bf16_128x128x64, p, stream);
         case GEMM_TILE_160: return launch_tile<Tile160>(ivit_gemm_bf16_160x128x64, p, stream);
+#ifdef IVIT_GEMM_ABLATIONS
         case GEMM_TILE_256: return launch_tile<Tile256>(ivit_gemm_bf16_256x256x64, p, stream);
         case GEMM_TILE_256P:
-#ifdef IVIT_GEMM_ABLATIONS
             if (p.debug == 1) return launch_tile<Tile256P>(ivit_gemm_256pipe_nodma, p, stream);
             if (p.debug == 2) return launch_tile<Tile256P>(ivit_gemm_256pipe_nomfma, p, stream);
-#endif
             return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_pipe, p, stream);
+        case GEMM_TILE_256PS:
+            if (p.K < 2 * GEMM_BK) return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag, p, stream);
+            return launch_persistent(p, stream);
+#endif
         case GEMM_TILE_256S:
 #ifdef IVIT_GEMM_ABLATIONS
             if (p.debug == 1) return launch_tile<Tile256P>(ivit_gemm_256stag_nodma, p, stream);
             if (p.debug == 2) return launch_tile<Tile256P>(ivit_gemm_256stag_nomfma, p, stream);
 #endif
             return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag, p, stream);
-        case GEMM_TILE_256PS:
-            if (p.K < 2 * GEMM_BK) return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag, p, stream);
-            return launch_persistent(p, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -1,0 +1,32 @@
+"""The RCCL leg on the GPU box (one GPU available here): bench.py's multi-rank code path with a
+world of ONE rank over backend "nccl" (= RCCL on ROCm) - process-group init on the device, the single
+all-gather of the packed [logits | class features] block, barrier + max-over-ranks timing.  The
+N = 2 logic itself is covered on CPU with gloo (tests/test_distributed.py); the N = 8 run is the
+driver's."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_runs_under_torchrun_with_rccl():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IVIT_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch-per-gpu", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["collective"] == "all_gather_into_tensor over nccl (RCCL), 1 per step"
+    assert d["parity"]["gathered_equals_local"] is True
