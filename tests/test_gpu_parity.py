@@ -224,3 +224,36 @@ def test_vit_b16_batch_parity_and_properties():
         assert torch.isfinite(logits).all()
     finally:
         eng.close()
+
+
+def test_vit_l16_384_long_sequence():
+    """BASELINE config 3 shapes (ViT-L/16 at 384^2: 577 tokens, D = 1024, 16 heads): the attention
+    kernel's 16-queries-per-wave / 608-key instantiation, LayerNorm<4>, K = 1024/4096 GEMMs.  The CPU
+    oracle is expensive here, so: strict per-node gate on two nodes for one image, plus the
+    size-independent properties (determinism, batch independence) on a ragged batch of 3."""
+    from interactive_vit_amd.engine import Engine
+    from oracle import vit_oracle
+    cfg = VARIANTS["vit_l_16_384"]
+    sd = init_weights(cfg, seed=0, mode="rich")
+    eng = Engine(cfg, sd, device=0, max_batch=3)
+    try:
+        x = synthetic_images(3, cfg, seed=77)
+        xg = x.cuda()
+        ns = len(eng.stages)
+        logits = eng.forward(xg, 0, ns)
+        assert torch.isfinite(logits).all()
+        assert torch.equal(logits, eng.forward(xg, 0, ns))
+        alone = eng.forward(xg[1:2].contiguous(), 0, ns)
+        assert torch.equal(alone[0], logits[1])
+        # strict gate: tokens -> encoder.layers.0 (attention over 577 keys) and conv_proj (K = 768 GEMM)
+        x1 = x[:1]
+        t = vit_oracle.transform(x1)
+        tok = vit_oracle.tokens(vit_oracle.conv_proj(t, sd, cfg), sd, cfg)
+        acts = {"transform": t, "conv_proj": vit_oracle.conv_proj(t, sd, cfg), "tokens": tok}
+        strict_nodes(eng, cfg, sd, acts, x1, ["conv_proj", "encoder.layers.0"])
+        # first layers of the chain stay inside the bf16 whole-chain bound
+        mid_ref = vit_oracle.encoder_layer(vit_oracle.encoder_layer(tok, sd, 0, cfg), sd, 1, cfg)
+        mid = eng.forward(x1.cuda(), 0, 5).cpu()
+        assert rel_err(mid, mid_ref) <= BF16_VS_F32_E2E
+    finally:
+        eng.close()
