@@ -96,6 +96,14 @@ int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end, int batch,
 int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_end, int batch,
                         const void* in, void* out, void* cls_out, void* stream);
 
+/* Attention probabilities of encoder layer `layer` for a residual-stream input [B,N,D] (f32, device):
+ * softmax(q k^T / sqrt(dh)) as f32 [B, heads, N, N] into `out` (device).  Backs the
+ * `<model>:encoder.layers.<i>.attn` node (attention maps the client's MultiView
+ * can display, multi_view.js:53-66); the reference has no counterpart. */
+int ivit_attention_map(ivit_engine* e, int layer, int batch, const void* in, void* out, void* stream);
+/* host-buffer form of the same (CPU f32 in / out; out_capacity in floats) */
+int ivit_attention_map_host(ivit_engine* e, int layer, int batch, const float* in, float* out, int64_t out_capacity);
+
 /* Inspection entry used by the parity tests: the bf16 unfold image [B*Np, Kpad] the patch GEMM
  * consumes, widened to f32 into `out` (device, B*Np*K floats, padding columns dropped).
  * normalise != 0 applies the transform first (the fused path), 0 unfolds the input as is. */

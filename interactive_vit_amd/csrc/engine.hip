@@ -130,6 +130,8 @@ struct ivit_engine {
     bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr, *hc = nullptr;
     float *x = nullptr, *clsf = nullptr, *ext_in = nullptr, *ext_out = nullptr, *upload = nullptr;
     int64_t ext_elems = 0, upload_elems = 0;
+    float* map_buf = nullptr;     // attention-map staging for the host path (grown on demand)
+    size_t map_bytes = 0;
 
     // profiling
     bool prof_on = false;
@@ -266,6 +268,7 @@ extern "C" void ivit_destroy(ivit_engine* e) {
         for (auto& sp : e->spans[c]) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
     for (void* p : e->allocs) (void)hipFree(p);
+    if (e->map_buf) (void)hipFree(e->map_buf);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (int i = 0; i < 2; ++i) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
@@ -397,6 +400,7 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B)
         ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = D;
         ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh;
         ap.scale = 1.0f / std::sqrt((float)e->dh);
+        ap.probs = nullptr;
         const double flops = 4.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh;
         ProfScope ps(e, PC_ATTN, st, flops, 2.0 * M * 4.0 * D);
         HIP_TRY(launch_attention(ap, st));
@@ -568,6 +572,56 @@ extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end,
     HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
     if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
     HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// caller holds e->mu and has set the device
+static int attention_map_locked(ivit_engine* e, int layer, int B, const float* in, float* out, hipStream_t st) {
+    if (require_weights(e)) return 1;
+    const int D = e->D, M = B * e->N;
+    LayerWeights& lw = e->layers[layer];
+    const Ws w = ws_slice(e, 0);
+    if (run_layernorm(e, st, in, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
+    if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
+    AttnParams ap{};
+    ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = D;
+    ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh;
+    ap.scale = 1.0f / std::sqrt((float)e->dh);
+    ap.probs = out;
+    ProfScope ps(e, PC_ATTN, st, 2.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh, 0.0);
+    HIP_TRY(launch_attention(ap, st));
+    return 0;
+}
+
+extern "C" int ivit_attention_map(ivit_engine* e, int layer, int batch, const void* in, void* out, void* stream) {
+    if (!e || !in || !out) return fail("ivit_attention_map: null argument");
+    if (layer < 0 || layer >= e->cfg.layers) return fail("layer %d outside 0..%d", layer, e->cfg.layers - 1);
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    return attention_map_locked(e, layer, batch, (const float*)in, (float*)out, (hipStream_t)stream);
+}
+
+extern "C" int ivit_attention_map_host(ivit_engine* e, int layer, int batch, const float* in, float* out, int64_t out_capacity) {
+    if (!e || !in || !out) return fail("ivit_attention_map_host: null argument");
+    if (layer < 0 || layer >= e->cfg.layers) return fail("layer %d outside 0..%d", layer, e->cfg.layers - 1);
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    const int64_t n_in = (int64_t)batch * e->N * e->D, n_out = (int64_t)batch * e->cfg.heads * e->N * e->N;
+    if (n_out > out_capacity) return fail("ivit_attention_map_host: output needs %lld floats, capacity is %lld", (long long)n_out, (long long)out_capacity);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->own_stream;
+    // the map ([heads,N,N] per image) can be larger than any stage tensor: it gets its own device buffer
+    const size_t need = (size_t)n_out * 4;
+    if (need > e->map_bytes) {
+        if (e->map_buf) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(e->map_buf); e->map_buf = nullptr; e->map_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&e->map_buf, need));
+        e->map_bytes = need;
+    }
+    HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
+    if (attention_map_locked(e, layer, batch, e->ext_in, e->map_buf, st)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, e->map_buf, need, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }

@@ -41,6 +41,7 @@ struct AttnParams {
     bf16_t* out; int ldo;          // [B*N, D] bf16
     int batch, tokens, heads, head_dim;
     float scale;                   // 1/sqrt(dh)
+    float* probs;                  // nullptr, or f32 [B, H, N, N]: write the attention probabilities instead of P.V
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 bool attention_supported(int tokens, int head_dim);

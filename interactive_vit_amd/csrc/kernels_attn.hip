@@ -40,7 +40,9 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
     return __builtin_bit_cast(bf16x4, v);
 }
 
-template <int NKF, int QB>
+// PROBS = true: the inspection variant behind the `encoder.layers.<i>.attn` node - same staging, QK^T and
+// softmax, but instead of P.V it writes the normalised probabilities as f32 [B, H, N, N].
+template <int NKF, int QB, bool PROBS>
 __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     using L = AttLayout<NKF, QB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -131,6 +133,21 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
 
+        if (PROBS) {   // lane holds P[q = qbase + fr][key = 16 f + 4 g + j]: a float4 per fragment
+            const int q = qbase + fr;
+            if (q < N) {
+                float* prow = p.probs + (((size_t)b * p.heads + h) * N + q) * N;
+#pragma unroll
+                for (int f = 0; f < NKF; ++f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = f * 16 + g * 4 + j;
+                        if (key < N) prow[key] = s[f][j] * inv;
+                    }
+            }
+            continue;
+        }
+
         // ---- O^T = V^T P^T
         f32x4 o[4];
 #pragma unroll
@@ -174,12 +191,12 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
 
 bool attention_supported(int tokens, int head_dim) { return head_dim == ATT_DH && tokens >= 1 && tokens <= 38 * 16; }
 
-template <int NKF, int QB>
-static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
+template <int NKF, int QB, bool PROBS>
+static hipError_t launch_nkf_impl(const AttnParams& p, hipStream_t stream) {
     using L = AttLayout<NKF, QB>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<NKF, QB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<NKF, QB, PROBS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -187,13 +204,18 @@ static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
     const int waves_needed = ceil_div(p.tokens, L::QPW);
     const int wpb = waves_needed < 8 ? waves_needed : 8;          // waves per workgroup
     dim3 grid(ceil_div(waves_needed, wpb), p.heads, p.batch);
-    hipLaunchKernelGGL((ivit_attention_bf16<NKF, QB>), grid, dim3(wpb * 64), L::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((ivit_attention_bf16<NKF, QB, PROBS>), grid, dim3(wpb * 64), L::LDS_BYTES, stream, p);
     return hipGetLastError();
+}
+
+template <int NKF, int QB>
+static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
+    return p.probs ? launch_nkf_impl<NKF, QB, true>(p, stream) : launch_nkf_impl<NKF, QB, false>(p, stream);
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (!attention_supported(p.tokens, p.head_dim)) return hipErrorInvalidValue;
-    if ((p.ldqkv % 8) || (p.ldo % 4)) return hipErrorInvalidValue;
+    if ((p.ldqkv % 8) || (!p.probs && (p.ldo % 4))) return hipErrorInvalidValue;
     const int nkf = round_up(ceil_div(p.tokens, 16), 2);
     if (nkf <= 2) return launch_nkf<2, 2>(p, stream);
     if (nkf <= 4) return launch_nkf<4, 2>(p, stream);

@@ -22,7 +22,8 @@ LIB_PATH = os.path.join(_HERE, "libivit.so")
 ABI_SYMBOLS = (
     "ivit_abi_version", "ivit_build_info", "ivit_last_error", "ivit_stage_count", "ivit_stage_shape",
     "ivit_unfold_offset", "ivit_create", "ivit_destroy", "ivit_set_weight", "ivit_weights_ready",
-    "ivit_forward_host", "ivit_forward_device", "ivit_debug_unfold", "ivit_profile_enable",
+    "ivit_forward_host", "ivit_forward_device", "ivit_attention_map", "ivit_attention_map_host",
+    "ivit_debug_unfold", "ivit_profile_enable",
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
 )
 
@@ -69,6 +70,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_weights_ready.argtypes = [c_p]
         lib.ivit_forward_host.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64]
         lib.ivit_forward_device.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
+        lib.ivit_attention_map.argtypes = [c_p, c_i, c_i, c_p, c_p, c_p]
+        lib.ivit_attention_map_host.argtypes = [c_p, c_i, c_i, c_p, c_p, c_i64]
         lib.ivit_debug_unfold.argtypes = [c_p, c_i, c_p, c_p, c_i, c_p]
         lib.ivit_profile_enable.argtypes = [c_p, c_i]
         lib.ivit_profile_reset.argtypes = [c_p]
@@ -204,9 +207,29 @@ class Engine:
                                                  ctypes.c_void_p(cls.data_ptr()) if cls is not None else None,
                                                  ctypes.c_void_p(stream)))
 
+    def attention_map(self, layer: int, x: torch.Tensor) -> torch.Tensor:
+        """softmax(q k^T / sqrt(dh)) of encoder layer `layer` for a residual-stream input
+        [N,D] / [B,N,D]: f32 [heads,N,N] / [B,heads,N,N] (CPU in -> CPU out, CUDA in -> CUDA out)."""
+        batch, batched = self._split_batch(x, 3)      # every encoder layer takes [N, D]
+        n, hds = self.cfg.tokens, self.cfg.heads
+        full = (batch, hds, n, n) if batched else (hds, n, n)
+        xin = x.detach().to(torch.float32).contiguous()
+        if x.device.type == "cpu":
+            out = torch.empty(full, dtype=torch.float32)
+            self._check(self.lib.ivit_attention_map_host(self._h, layer, batch, ctypes.c_void_p(xin.data_ptr()),
+                                                         ctypes.c_void_p(out.data_ptr()), out.numel()))
+            return out
+        out = torch.empty(full, dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        self._check(self.lib.ivit_attention_map(self._h, layer, batch, ctypes.c_void_p(xin.data_ptr()),
+                                                ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
+        return out
+
     def run_node(self, suffix: str, x: torch.Tensor) -> torch.Tensor:
         if suffix == "forward":
             return self.forward(x, 0, len(self.stages))
+        if suffix.endswith(".attn"):
+            return self.attention_map(int(suffix.split(".")[-2]), x)
         s = self.stage_index(suffix)
         return self.forward(x, s, s + 1)
 

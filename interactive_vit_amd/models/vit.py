@@ -4,8 +4,10 @@
 
 Nodes (``<name>:`` prefix): ``transform``, ``conv_proj``, ``tokens``, ``encoder.layers.<i>``
 (residual-inclusive: the server graph cannot fan out), ``encoder.ln``, ``cls``,
-``heads`` - a linear chain that ends in a client-side ``category`` node - and the standalone
-``forward`` node (whole model in one launch sequence).  Every node takes one input "o" and gives
+``heads`` - a linear chain that ends in a client-side ``category`` node - the standalone
+``forward`` node (whole model in one launch sequence), and ``encoder.layers.<i>.attn`` inspectors
+(``[N,D]`` residual stream in, attention probabilities ``[heads,N,N]`` out - a ``[C,H,W]`` tensor the
+client's MultiView displays).  Every node takes one input "o" and gives
 one output "o"; images are unbatched ``[3,S,S]`` in the interactive path, a leading batch axis is
 accepted everywhere.
 
@@ -84,8 +86,14 @@ def make_vit_model_class(ModelBase, PinoutCls):
         def chain_node_names(self) -> List[str]:
             return [self.prefix() + s for s in self._suffixes]
 
+        def attn_node_names(self) -> List[str]:
+            return [f"{self.prefix()}encoder.layers.{i}.attn" for i in range(self.cfg.layers)]
+
         def list_node_names(self) -> List[str]:
-            return self.chain_node_names() + [self.prefix() + "forward"]
+            # the chain, the fused whole model, and one attention-map inspector per encoder layer
+            # ([N,D] -> [heads,N,N]; put it in place of layer i at the end of a shorter chain: the
+            # server graph cannot fan out)
+            return self.chain_node_names() + [self.prefix() + "forward"] + self.attn_node_names()
 
         def generate_graph_json(self) -> Dict:
             """Chain graph in the client's schema (graph.js:700-758), laid out exactly like
@@ -112,7 +120,7 @@ def make_vit_model_class(ModelBase, PinoutCls):
             x = pinin.get("o")
             assert x is not None
             suffix = node_name.removeprefix(self.prefix())
-            if suffix != "forward" and suffix not in self._suffixes:
+            if suffix != "forward" and suffix not in self._suffixes and node_name not in self.attn_node_names():
                 raise KeyError(node_name)
             with torch.no_grad():
                 y = self.backend.run_node(suffix, x)
@@ -132,7 +140,8 @@ def make_vit_model_class(ModelBase, PinoutCls):
                 "cls": f"token 0 &rarr; [{c.dim}]",
                 "heads": f"Linear &rarr; [{c.classes}]",
                 "forward": f"whole model &rarr; [{c.classes}]",
-            }.get(suffix, f"MHSA({c.heads} heads) + MLP({c.mlp})")
+            }.get(suffix, f"attention map &rarr; [{c.heads},{c.tokens},{c.tokens}]" if suffix.endswith(".attn")
+                  else f"MHSA({c.heads} heads) + MLP({c.mlp})")
             return f"<p>{node_name}</p> <p>{detail}</p>"
 
         def io(self, node_name: str) -> Dict:

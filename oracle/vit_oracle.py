@@ -165,6 +165,14 @@ def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False, emul
     return (out, p) if return_probs else out
 
 
+def attention_map(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> torch.Tensor:
+    """Attention probabilities of layer i for a residual-stream input: [B,N,D] -> [B,H,N,N]."""
+    dt = x.dtype
+    pre = layer_prefix(i)
+    h = rnd(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), emulate)
+    return attention(h, sd, i, cfg, return_probs=True, emulate=emulate)[1]
+
+
 def encoder_layer(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> torch.Tensor:
     """Residual-inclusive block i: [B,N,D] -> [B,N,D]."""
     dt = x.dtype
@@ -205,6 +213,8 @@ def run_node(suffix: str, x: torch.Tensor, sd, cfg, emulate: bool = False) -> to
         return conv_proj(x, sd, cfg, emulate)
     if suffix == "tokens":
         return tokens(x, sd, cfg)
+    if suffix.startswith("encoder.layers.") and suffix.endswith(".attn"):
+        return attention_map(x, sd, int(suffix.split(".")[-2]), cfg, emulate)
     if suffix.startswith("encoder.layers."):
         return encoder_layer(x, sd, int(suffix.rsplit(".", 1)[1]), cfg, emulate)
     if suffix == "encoder.ln":
@@ -244,7 +254,7 @@ INPUT_RANK = {"transform": 3, "conv_proj": 3, "tokens": 2, "encoder.ln": 2, "cls
 
 
 def input_rank(suffix: str) -> int:
-    return 2 if suffix.startswith("encoder.layers.") else INPUT_RANK[suffix]
+    return 2 if suffix.startswith("encoder.layers.") else INPUT_RANK[suffix]   # incl. the .attn inspectors
 
 
 def run_node_any(suffix: str, x: torch.Tensor, sd, cfg, emulate: bool = False) -> torch.Tensor:

@@ -257,3 +257,38 @@ def test_vit_l16_384_long_sequence():
         assert rel_err(mid, mid_ref) <= BF16_VS_F32_E2E
     finally:
         eng.close()
+
+
+def test_attention_map_nodes(small):
+    """`encoder.layers.<i>.attn`: [N,D] -> [heads,N,N] attention probabilities."""
+    from oracle import vit_oracle
+    cfg, sd, eng = small
+    x = synthetic_images(3, cfg, seed=12)
+    acts = vit_oracle.forward(x, sd, cfg, keep=True)
+    for layer in range(cfg.layers):
+        node_in = acts["tokens"] if layer == 0 else acts[f"encoder.layers.{layer - 1}"]
+        emu = vit_oracle.attention_map(node_in.double(), sd, layer, cfg, emulate=True)
+        got = eng.run_node(f"encoder.layers.{layer}.attn", node_in.cuda()).cpu()
+        assert got.shape == (3, cfg.heads, cfg.tokens, cfg.tokens)
+        assert rel_err(got, emu) <= REL_TOL
+        assert torch.allclose(got.sum(-1), torch.ones(3, cfg.heads, cfg.tokens), atol=1e-5)   # rows are distributions
+        one = eng.run_node(f"encoder.layers.{layer}.attn", node_in[0])                          # unbatched, host path
+        assert one.shape == (cfg.heads, cfg.tokens, cfg.tokens) and one.device.type == "cpu"
+        assert torch.equal(one, got[0])
+
+
+def test_attention_map_197_tokens():
+    from interactive_vit_amd.engine import Engine
+    from oracle import vit_oracle
+    cfg = VARIANTS["vit_ti_16"]
+    sd = init_weights(cfg, seed=0, mode="rich")
+    eng = Engine(cfg, sd, device=0, max_batch=2)
+    try:
+        x = synthetic_images(2, cfg, seed=5)
+        tok = vit_oracle.forward(x, sd, cfg, keep=True)["tokens"]
+        emu = vit_oracle.attention_map(tok.double(), sd, 0, cfg, emulate=True)
+        got = eng.attention_map(0, tok.cuda()).cpu()
+        assert got.shape == (2, cfg.heads, 197, 197)
+        assert rel_err(got, emu) <= REL_TOL
+    finally:
+        eng.close()

@@ -32,7 +32,8 @@ def plugin(tmp_path):
 def test_registration_and_graph_file(plugin):
     cfg, sd, vit, ctx, base = plugin
     names = vit.list_node_names()
-    assert names == [f"{cfg.name}:{s}" for s in node_suffixes(cfg)] + [f"{cfg.name}:forward"]
+    assert names == ([f"{cfg.name}:{s}" for s in node_suffixes(cfg)] + [f"{cfg.name}:forward"]
+                     + [f"{cfg.name}:encoder.layers.{i}.attn" for i in range(cfg.layers)])
     assert sorted(ctx.nodes) == sorted(names)
     assert all("/" not in n for n in names)             # node names are URL path segments (urls.py:12-13)
     gj = json.load(open(base / "static" / "graphs" / f"{cfg.name}.json"))
@@ -65,6 +66,23 @@ def test_chain_through_context_matches_direct_forward(plugin):
     # shapes the browser viewers rely on
     assert nodes[0].get_pinout().get("o").shape == (3, cfg.image, cfg.image)
     assert nodes[2].get_pinout().get("o").shape == (cfg.tokens, cfg.dim)
+
+
+def test_attention_map_node_shapes(plugin):
+    cfg, sd, vit, ctx, _ = plugin
+    img = synthetic_images(1, cfg, seed=9)[0]
+    g = Graph()
+    chain = [f"{cfg.name}:transform", f"{cfg.name}:conv_proj", f"{cfg.name}:tokens", f"{cfg.name}:encoder.layers.0",
+             f"{cfg.name}:encoder.layers.1.attn"]
+    nodes = [g.add_node(n, {}) for n in chain]
+    for a, b in zip(nodes, nodes[1:]):
+        g.connect(a, "o", b, "o")
+    g.add_input(img, nodes[0], "o")
+    ctx.compute(g)
+    amap = nodes[-1].get_pinout().get("o")
+    assert amap.shape == (cfg.heads, cfg.tokens, cfg.tokens)          # [C,H,W]: what MultiView displays
+    assert torch.allclose(amap.sum(-1), torch.ones(cfg.heads, cfg.tokens), atol=1e-5)
+    assert ctx.get_node(chain[-1]).contents({}).startswith(f"<p>{chain[-1]}</p>")
 
 
 def test_missing_input_and_unknown_node(plugin):

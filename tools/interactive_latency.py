@@ -1,0 +1,37 @@
+"""Latency of the interactive path: one /compute request (wire bytes in -> wire bytes out) for a
+single 224x224 image through the whole ViT-B/16 node chain on the GPU plugin, and through the
+fused `forward` node alone.  Host buffers cross PCIe here (this is NOT bench.py's `value`)."""
+import os, sys, time, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from interactive_vit_amd import context as ctxmod
+from interactive_vit_amd.context import Context, Model
+from interactive_vit_amd.graph import Pinout
+from interactive_vit_amd.message import encode_request, decode_response
+from interactive_vit_amd.models.vit import HipBackend, make_vit_model_class
+from interactive_vit_amd.views import compute_bytes
+from interactive_vit_amd.vit_config import VARIANTS
+from interactive_vit_amd.weights import init_weights, synthetic_images
+
+base = tempfile.mkdtemp(); os.makedirs(os.path.join(base, "static", "graphs")); ctxmod.set_base_dir(base)
+cfg = VARIANTS[sys.argv[1] if len(sys.argv) > 1 else "vit_b_16"]
+sd = init_weights(cfg, 0)
+vit = make_vit_model_class(Model, Pinout)(cfg, HipBackend(cfg, sd, device=0, max_batch=1))
+ctx = Context(); vit.register(ctx)
+img = synthetic_images(1, cfg, 1)[0]
+chain = vit.chain_node_names()
+def req_chain():
+    nodes = [{"endpoint": n, "params": {}} for n in chain]
+    edges = [{"tensor": 0, "out_port": {"node": 0, "channel": "o"}}] + [
+        {"in_port": {"node": i, "channel": "o"}, "out_port": {"node": i + 1, "channel": "o"}} for i in range(len(chain) - 1)]
+    return encode_request(nodes, edges, [img])
+def req_fwd():
+    return encode_request([{"endpoint": f"{cfg.name}:forward", "params": {}}], [{"tensor": 0, "out_port": {"node": 0, "channel": "o"}}], [img])
+for label, mk in (("node chain (%d nodes, every output returned)" % len(chain), req_chain), ("fused forward node", req_fwd)):
+    body = mk()
+    for _ in range(5): st, out = compute_bytes(body, ctx); assert st == 200
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter(); st, out = compute_bytes(body, ctx); ts.append(time.perf_counter() - t0)
+    ts.sort()
+    print(f"{cfg.name} {label}: median {ts[len(ts)//2]*1e3:.2f} ms, p10 {ts[3]*1e3:.2f} ms, request {len(body)/1e6:.2f} MB, response {len(out)/1e6:.2f} MB")
