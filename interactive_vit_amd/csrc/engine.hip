@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 using namespace ivit;
@@ -132,6 +133,12 @@ struct ivit_engine {
     int64_t ext_elems = 0, upload_elems = 0;
     float* map_buf = nullptr;     // attention-map staging for the host path (grown on demand)
     size_t map_bytes = 0;
+    // hipGraph cache of the host path: a small-batch forward is ~90 launches of microsecond kernels
+    // (launch-bound), and its buffers (ext_in / ext_out / workspaces) never move, so the launch
+    // sequence of a (stage range, batch) is captured once and replayed.  IVIT_GRAPHS=0 disables.
+    bool graphs_on = true;
+    int graph_max_batch = 4;
+    std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
 
     // profiling
     bool prof_on = false;
@@ -212,6 +219,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         // all kernels queue on the same per-CU vector-memory path - so it is off by default.
         const char* sp = getenv("IVIT_SPLIT");
         e->split = sp ? atoi(sp) : 1;
+        const char* gr = getenv("IVIT_GRAPHS");
+        e->graphs_on = !(gr && atoi(gr) == 0);
         if (e->split < 1 || e->split > 2) e->split = 1;
         for (int i = 0; i < 2; ++i) {
             if (hipStreamCreateWithFlags(&e->aux_stream[i], hipStreamNonBlocking) != hipSuccess ||
@@ -267,6 +276,7 @@ extern "C" void ivit_destroy(ivit_engine* e) {
     for (int c = 0; c < PC_COUNT; ++c)
         for (auto& sp : e->spans[c]) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
+    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->map_buf) (void)hipFree(e->map_buf);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -570,7 +580,35 @@ extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end,
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = e->own_stream;
     HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
-    if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
+    const bool use_graph = e->graphs_on && !e->prof_on && batch <= e->graph_max_batch && (stage_end - stage_begin) > 1;
+    if (use_graph) {
+        if (require_weights(e)) return 1;
+        const auto key = std::make_tuple(stage_begin, stage_end, batch);
+        auto it = e->graphs.find(key);
+        if (it == e->graphs.end()) {
+            // first request of this shape: run it eagerly (this also performs every one-time
+            // hipFuncSetAttribute outside of a capture), then capture the same launch sequence on the
+            // engine's own stream for the following requests (nothing in it syncs or allocates)
+            if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
+            HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st);
+            const hipError_t ce = hipStreamEndCapture(st, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
+            if (ce != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            hipGraphExec_t exec = nullptr;
+            const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+            e->graphs.emplace(key, exec);
+            return 0;   // the eager run above already produced this request's output
+        }
+        HIP_TRY(hipGraphLaunch(it->second, st));
+    } else {
+        if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
+    }
     HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return 0;

@@ -292,3 +292,25 @@ def test_attention_map_197_tokens():
         assert rel_err(got, emu) <= REL_TOL
     finally:
         eng.close()
+
+
+def test_host_path_graph_replay_is_bit_identical(small):
+    """Small-batch requests on the host-buffer entry replay a captured hipGraph from the second
+    call on; results must equal the eager first call bit for bit, for several stage ranges, and a
+    different input must give a different (correct) output through the same graph."""
+    from oracle import vit_oracle
+    cfg, sd, eng = small
+    ns = len(eng.stages)
+    x1 = synthetic_images(1, cfg, seed=31)[0]
+    x2 = synthetic_images(1, cfg, seed=32)[0]
+    for (b, e_) in ((0, ns), (0, 5), (3, ns)):
+        src1 = x1 if b == 0 else vit_oracle.forward(x1.unsqueeze(0), sd, cfg, keep=True)["tokens"][0]
+        src2 = x2 if b == 0 else vit_oracle.forward(x2.unsqueeze(0), sd, cfg, keep=True)["tokens"][0]
+        first = eng.forward(src1, b, e_)            # eager + capture
+        again = eng.forward(src1, b, e_)            # graph replay
+        third = eng.forward(src1, b, e_)
+        assert torch.equal(first, again) and torch.equal(first, third)
+        other = eng.forward(src2, b, e_)            # same graph, new input bytes
+        assert not torch.equal(other, first)
+        dev = eng.forward(src2.cuda(), b, e_).cpu() # device path never uses graphs
+        assert torch.equal(other, dev)
