@@ -59,21 +59,47 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     const bf16_t* qkv = p.qkv;
     const int ld = p.ldqkv;
 
-    // ---- stage K and V (row-major, 16-B chunks; rows >= N are zero: 0 * garbage must not be NaN)
-    for (int c = threadIdx.x; c < L::KEYS * 8; c += blockDim.x) {
-        const int key = c >> 3, ch = c & 7;
-        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (key < N) {
-            const bf16_t* src = qkv + (row0 + key) * ld + h * ATT_DH + ch * 8;
-            kv = *reinterpret_cast<const u32x4*>(src + D);
-            vv = *reinterpret_cast<const u32x4*>(src + 2 * D);
+    const int q0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * L::QPW;
+
+    // ---- Q fragments of the wave's first query block: issued BEFORE the staging barrier so that their
+    // latency overlaps the K/V staging (B operand: lane holds Q[q + fr][kk*32 + 8g .. +7])
+    bf16x8 qf[2];
+    {
+        const int qrow = min(q0 + fr, N - 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8);
+    }
+
+    // ---- stage K and V (row-major, 16-B chunks; rows >= N are zero: 0 * garbage must not be NaN).
+    // Batches of 4 chunks per thread: all 8 global loads of a batch are in flight before the first
+    // LDS store (a plain loop serialised load -> wait -> store per chunk).
+    for (int c0 = threadIdx.x; c0 < L::KEYS * 8; c0 += 4 * blockDim.x) {
+        u32x4 kv[4], vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + i * blockDim.x;
+            const int key = c >> 3, ch = c & 7;
+            kv[i] = u32x4{0u, 0u, 0u, 0u};
+            vv[i] = u32x4{0u, 0u, 0u, 0u};
+            if (c < L::KEYS * 8 && key < N) {
+                const bf16_t* src = qkv + (row0 + key) * ld + h * ATT_DH + ch * 8;
+                kv[i] = *reinterpret_cast<const u32x4*>(src + D);
+                vv[i] = *reinterpret_cast<const u32x4*>(src + 2 * D);
+            }
         }
-        *reinterpret_cast<u32x4*>(k_lds + key * 128 + ((ch ^ (key & 7)) << 4)) = kv;
-        *reinterpret_cast<u32x4*>(v_lds + key * 128 + ((ch ^ (((key >> 1) & 3) << 1)) << 4)) = vv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + i * blockDim.x;
+            const int key = c >> 3, ch = c & 7;
+            if (c < L::KEYS * 8) {
+                *reinterpret_cast<u32x4*>(k_lds + key * 128 + ((ch ^ (key & 7)) << 4)) = kv[i];
+                *reinterpret_cast<u32x4*>(v_lds + key * 128 + ((ch ^ (((key >> 1) & 3) << 1)) << 4)) = vv[i];
+            }
+        }
     }
     __syncthreads();
 
-    const int q0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * L::QPW;
     if (q0 >= N) return;  // whole wave idle (after the only barrier)
 
     // transposed-read addressing: lane i = 4q + p of its 16-lane group supplies &V[key0 + q][d0 + 4p]
@@ -87,12 +113,12 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     for (int c = 0; c < QB; ++c) {
         const int qbase = q0 + c * 16;
         if (qbase >= N) break;   // wave-uniform
-        // ---- Q fragments (B operand): lane holds Q[qbase + fr][kk*32 + 8g .. +7]
-        const int qrow = min(qbase + fr, N - 1);
-        bf16x8 qf[2];
+        if (c > 0) {   // later blocks: plain load (the first block's fragments were prefetched above)
+            const int qrow = min(qbase + fr, N - 1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8);
+            for (int kk = 0; kk < 2; ++kk)
+                qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8);
+        }
 
         // ---- S^T = K Q^T
         f32x4 s[NKF];

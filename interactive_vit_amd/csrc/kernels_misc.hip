@@ -125,9 +125,12 @@ hipError_t launch_tokens(const float* in, const float* cls, const float* pos, fl
 }
 
 // ---------------------------------------------------------------------------- LayerNorm
-// One wavefront per row; the row (dim <= 64*4*VPL floats) stays in registers between the two
-// statistics passes (mean, then centred variance - the same two-pass form as the oracle), so x is
-// read from HBM once.  Reductions are 64-lane xor-shuffles.
+// One wavefront per LN_RPW rows; every row (dim <= 64*4*VPL floats) stays in registers between the
+// two statistics passes (mean, then centred variance - the same two-pass form as the oracle), so x
+// is read from HBM once.  All LN_RPW rows' loads are issued before the first reduction (the
+// one-row-per-wave version spent 70 % of its wave cycles waiting on its single load batch).
+// Reductions are 64-lane xor-shuffles.
+constexpr int LN_RPW = 2;   // rows per wave (ViT-B/16, B=64, 25 launches: 1 row 0.348 ms, 2 rows 0.328 ms, 4 rows 0.386 ms)
 template <int VPL>  // float4 vectors per lane
 __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ x, int ldx, int64_t row_stride, int rows,
                                                       int dim, const float* __restrict__ gamma,
@@ -135,44 +138,59 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
                                                       bf16_t* __restrict__ o16, int ldo16, float* __restrict__ o32,
                                                       int ldo32) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + (size_t)row * row_stride * ldx;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
+    if (row0 >= rows) return;
     const int d4 = dim >> 2;
-    float4 v[VPL];
-    float sum = 0.f;
+    float4 v[LN_RPW][VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int c = i * 64 + lane;
-        v[i] = (c < d4) ? reinterpret_cast<const float4*>(xr)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-    const float mean = wave_sum(sum) / (float)dim;
-    float sq = 0.f;
+    for (int r = 0; r < LN_RPW; ++r) {
+        const int row = min(row0 + r, rows - 1);          // clamp: the surplus rows are loaded, never stored
+        const float* xr = x + (size_t)row * row_stride * ldx;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int c = i * 64 + lane;
-        if (c < d4) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            sq += (a * a + b * b) + (cc * cc + d * d);
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            v[r][i] = (c < d4) ? reinterpret_cast<const float4*>(xr)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)dim + eps);
+    float4 gm[VPL], bt[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = i * 64 + lane;
-        if (c < d4) {
-            const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
-            const float4 bt = reinterpret_cast<const float4*>(beta)[c];
-            float4 y;
-            y.x = (v[i].x - mean) * rstd * gm.x + bt.x;
-            y.y = (v[i].y - mean) * rstd * gm.y + bt.y;
-            y.z = (v[i].z - mean) * rstd * gm.z + bt.z;
-            y.w = (v[i].w - mean) * rstd * gm.w + bt.w;
-            if (o32) reinterpret_cast<float4*>(o32 + (size_t)row * ldo32)[c] = y;
-            if (o16) {
-                u32x2 pk = {pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
-                reinterpret_cast<u32x2*>(o16 + (size_t)row * ldo16)[c] = pk;
+        gm[i] = (c < d4) ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[i] = (c < d4) ? reinterpret_cast<const float4*>(beta)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < LN_RPW; ++r) {
+        const int row = row0 + r;
+        if (row >= rows) break;   // wave-uniform
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) sum += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+        const float mean = wave_sum(sum) / (float)dim;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                const float a = v[r][i].x - mean, b = v[r][i].y - mean, cc = v[r][i].z - mean, d = v[r][i].w - mean;
+                sq += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)dim + eps);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = i * 64 + lane;
+            if (c < d4) {
+                float4 y;
+                y.x = (v[r][i].x - mean) * rstd * gm[i].x + bt[i].x;
+                y.y = (v[r][i].y - mean) * rstd * gm[i].y + bt[i].y;
+                y.z = (v[r][i].z - mean) * rstd * gm[i].z + bt[i].z;
+                y.w = (v[r][i].w - mean) * rstd * gm[i].w + bt[i].w;
+                if (o32) reinterpret_cast<float4*>(o32 + (size_t)row * ldo32)[c] = y;
+                if (o16) {
+                    u32x2 pk = {pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
+                    reinterpret_cast<u32x2*>(o16 + (size_t)row * ldo16)[c] = pk;
+                }
             }
         }
     }
@@ -183,7 +201,7 @@ hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int row
                             hipStream_t s) {
     if (dim % 4 || dim > 64 * 4 * 8) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
-    const dim3 grid(ceil_div(rows, 4)), block(256);
+    const dim3 grid(ceil_div(rows, 4 * LN_RPW)), block(256);
     const int vpl = ceil_div(dim / 4, 64);
 #define IVIT_LN(V) hipLaunchKernelGGL(ivit_layernorm<V>, grid, block, 0, s, x, ldx, row_stride, rows, dim, gamma, beta, eps, o16, ldo16, o32, ldo32)
     if (vpl <= 1) IVIT_LN(1);
