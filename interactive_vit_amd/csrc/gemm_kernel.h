@@ -98,6 +98,31 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
 #pragma unroll
             for (int j = 0; j < T::FN; ++j) extra[j] = *reinterpret_cast<const float4*>(src + n_base + j * 16 + fq * 4);
         }
+        if (INTERIOR && (T::FN % 2 == 0) && (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16)) {
+            // bf16 output, interior tile: 16-byte stores.  A lane holds 4 consecutive n per fragment
+            // (8 B of bf16); v_permlane16_swap trades quads between the lane rows fq and fq^1 of a
+            // fragment PAIR (j, j+1): even-fq lanes end up with 8 consecutive n of fragment j, odd-fq
+            // lanes with 8 consecutive n of fragment j+1.  Same bytes, half the store instructions -
+            // the 8-byte form is store-ISSUE-bound (~7 B/clk/CU: 7.5 us per 256x256 tile, stamps).
+            // Semantics pinned on hardware by tools/permlane_probe.hip.
+            bf16_t* orow_p = reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo;
+#pragma unroll
+            for (int j = 0; j < T::FN; j += 2) {
+                float a[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+                float b[4] = {acc[i][j + 1][0] + bias4[j + 1].x, acc[i][j + 1][1] + bias4[j + 1].y,
+                              acc[i][j + 1][2] + bias4[j + 1].z, acc[i][j + 1][3] + bias4[j + 1].w};
+                if (epi == EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a[r] = gelu_erf(a[r]); b[r] = gelu_erf(b[r]); }
+                }
+                const auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1]), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[2], a[3]), pack_bf16x2(b[2], b[3]), false, false);
+                const int n = n_base + (j + (fq & 1)) * 16 + (fq & ~1) * 4;
+                u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
+                *reinterpret_cast<u32x4*>(orow_p + n) = pk;
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < T::FN; ++j) {
             const int n = n_base + j * 16 + fq * 4;
