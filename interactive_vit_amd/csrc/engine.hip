@@ -119,6 +119,11 @@ struct ivit_engine {
     int split = 1, split_min_batch = 16;
     hipStream_t aux_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    // The activation workspaces are shared by every call, and calls may arrive on different streams
+    // (the host-buffer entry uses own_stream, the device entry the caller's): each call's stream
+    // first waits for the event the previous call recorded when it finished with the workspaces.
+    hipEvent_t ev_ws = nullptr;
+    bool ws_used = false;
     std::vector<void*> allocs;
     std::map<std::string, bool> have;
     bool weights_complete = false;
@@ -226,7 +231,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
             if (hipStreamCreateWithFlags(&e->aux_stream[i], hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("aux stream/event creation failed"); }
         }
-        if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("event creation failed"); }
+        if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_ws, hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("event creation failed"); }
     }
     chk(alloc_matrix(e, &e->w_patch, D, e->K));
     chk(alloc_vec(e, &e->b_patch, D));
@@ -285,6 +291,7 @@ extern "C" void ivit_destroy(ivit_engine* e) {
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_ws) (void)hipEventDestroy(e->ev_ws);
     delete e;
 }
 
@@ -523,6 +530,17 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
     return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes);
 }
 
+// workspace hand-over between calls on (possibly) different streams; caller holds e->mu
+static int ws_acquire(ivit_engine* e, hipStream_t st) {
+    if (e->ws_used) HIP_TRY(hipStreamWaitEvent(st, e->ev_ws, 0));
+    return 0;
+}
+static int ws_release(ivit_engine* e, hipStream_t st) {
+    HIP_TRY(hipEventRecord(e->ev_ws, st));
+    e->ws_used = true;
+    return 0;
+}
+
 static Ws ws_slice(ivit_engine* e, int b0) {
     const size_t rt = (size_t)b0 * e->N, rp = (size_t)b0 * e->Np;
     Ws w;
@@ -566,7 +584,11 @@ extern "C" int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_en
     if (!in || !out) return fail("ivit_forward_device: null buffer");
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
-    return forward_locked(e, stage_begin, stage_end, batch, (const float*)in, (float*)out, (float*)cls_out, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (ws_acquire(e, st)) return 1;
+    const int rc = forward_locked(e, stage_begin, stage_end, batch, (const float*)in, (float*)out, (float*)cls_out, st);
+    if (ws_release(e, st)) return 1;
+    return rc;
 }
 
 extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end, int batch, const float* in, float* out,
@@ -579,6 +601,7 @@ extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end,
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = e->own_stream;
+    if (ws_acquire(e, st)) return 1;
     HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
     const bool use_graph = e->graphs_on && !e->prof_on && batch <= e->graph_max_batch && (stage_end - stage_begin) > 1;
     if (use_graph) {
@@ -603,13 +626,14 @@ extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end,
             (void)hipGraphDestroy(graph);
             if (ie != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(ie));
             e->graphs.emplace(key, exec);
-            return 0;   // the eager run above already produced this request's output
+            return ws_release(e, st);   // the eager run above already produced this request's output
         }
         HIP_TRY(hipGraphLaunch(it->second, st));
     } else {
         if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
     }
     HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    if (ws_release(e, st)) return 1;
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
@@ -638,7 +662,11 @@ extern "C" int ivit_attention_map(ivit_engine* e, int layer, int batch, const vo
     if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
-    return attention_map_locked(e, layer, batch, (const float*)in, (float*)out, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (ws_acquire(e, st)) return 1;
+    const int rc = attention_map_locked(e, layer, batch, (const float*)in, (float*)out, st);
+    if (ws_release(e, st)) return 1;
+    return rc;
 }
 
 extern "C" int ivit_attention_map_host(ivit_engine* e, int layer, int batch, const float* in, float* out, int64_t out_capacity) {
@@ -657,9 +685,11 @@ extern "C" int ivit_attention_map_host(ivit_engine* e, int layer, int batch, con
         HIP_TRY(hipMalloc((void**)&e->map_buf, need));
         e->map_bytes = need;
     }
+    if (ws_acquire(e, st)) return 1;
     HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
     if (attention_map_locked(e, layer, batch, e->ext_in, e->map_buf, st)) return 1;
     HIP_TRY(hipMemcpyAsync(out, e->map_buf, need, hipMemcpyDeviceToHost, st));
+    if (ws_release(e, st)) return 1;
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
@@ -670,9 +700,10 @@ extern "C" int ivit_debug_unfold(ivit_engine* e, int batch, const void* in, void
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
+    if (ws_acquire(e, st)) return 1;
     HIP_TRY(launch_unfold((const float*)in, e->patches, batch, e->cfg.image, e->cfg.patch, e->Kp, normalise ? 1 : 0, st));
     HIP_TRY(launch_bf16_to_f32(e->patches, e->Kp, (float*)out, batch * e->Np, e->K, st));
-    return 0;
+    return ws_release(e, st);
 }
 
 // ------------------------------------------------------------------------------------ profiling

@@ -314,3 +314,34 @@ def test_host_path_graph_replay_is_bit_identical(small):
         assert not torch.equal(other, first)
         dev = eng.forward(src2.cuda(), b, e_).cpu() # device path never uses graphs
         assert torch.equal(other, dev)
+
+
+def test_concurrent_compute_from_many_threads(small):
+    """Django serves /compute on concurrent threads and the reference takes no locks:
+    one engine must give every thread its own correct answer.  Calls are serialised inside the
+    library; ctypes releases the GIL around them."""
+    import threading
+    cfg, sd, eng = small
+    ns = len(eng.stages)
+    inputs = [synthetic_images(1 + (i % 3), cfg, seed=100 + i) for i in range(8)]
+    expected = [eng.forward(x, 0, ns) for x in inputs]                    # sequential, host path
+    results = [[None] * 6 for _ in inputs]
+    errors = []
+
+    def worker(i):
+        try:
+            for rep in range(6):
+                x = inputs[i] if rep % 2 == 0 else inputs[i].cuda()       # mix host and device entry points
+                results[i][rep] = eng.forward(x, 0, ns).cpu()
+        except Exception as ex:  # noqa
+            errors.append(ex)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(inputs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, exp in enumerate(expected):
+        for got in results[i]:
+            assert torch.equal(got, exp), f"thread {i} got another request's result"
