@@ -30,3 +30,27 @@ def test_bench_runs_under_torchrun_with_rccl():
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["collective"] == "all_gather_into_tensor over nccl (RCCL), 1 per step"
     assert d["parity"]["gathered_equals_local"] is True
+
+
+def test_bench_json_contract_single_gpu():
+    """`python bench.py` (N = 1): one JSON line with the contract's keys, the roofline and
+    cpu_baseline objects, and the parity gate evaluated in the same run."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "images/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert "vit_b_16" in d["config"]["workload"] and d["config"]["batch_per_gpu"] == 64 and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2516.6
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.05 < rf["frac"] < 1.0
+    assert abs(d["value"] - 64 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.01
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "images/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["parity"]["logits_vs_plain_f32_oracle"] <= d["parity"]["bound_whole_forward_bf16"]
