@@ -202,7 +202,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     const int dh = cfg->dim / cfg->heads;
     const int g = cfg->image / cfg->patch;
     if (!attention_supported(g * g + 1, dh))
-        return fail("ivit_create: attention kernel supports head_dim 64 and <= 608 tokens (got head_dim %d, %d tokens)", dh, g * g + 1);
+        return fail("ivit_create: attention kernel supports head_dim 64 (<= 608 tokens) or 80 (<= 416 tokens); got head_dim %d, %d tokens", dh, g * g + 1);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail("ivit_create: device %d not present (%d visible)", cfg->device, ndev);

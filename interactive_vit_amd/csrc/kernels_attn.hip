@@ -1,4 +1,4 @@
-// Multi-head self-attention core for ViT token counts (up to 608 keys), head dim 64:
+// Multi-head self-attention core for ViT token counts (up to 608 keys), head dim 64 or 80:
 //
 //     out[b, q, h*64 + d] = sum_key softmax_key(scale * Q[q].K[key]) * V[key][d]
 //
@@ -23,15 +23,23 @@
 
 namespace ivit {
 
-constexpr int ATT_DH = 64;
-
-template <int NKF, int QB>
+// Head dims: 64 (ViT-Ti/B/L: 128-B LDS rows, XOR-swizzled chunks) and 80 (ViT-H/14: 160 B of data in
+// 176-B rows - an odd number of 16-B chunks spreads rows over the banks without a swizzle; the
+// third 32-deep MFMA step of Q.K^T covers d = 64..95 with 80..95 supplied as zero fragments).
+template <int DH, int NKF, int QB>
 struct AttLayout {
+    static_assert(DH == 64 || DH == 80, "head dim 64 or 80");
     static constexpr int KEYS = NKF * 16;
-    static constexpr int K_BYTES = KEYS * 128;
-    static constexpr int V_BYTES = KEYS * 128;
+    static constexpr int ROW = (DH == 64) ? 128 : 176;       // LDS row stride in bytes
+    static constexpr int CHUNKS = DH / 8;                     // 16-B chunks of data per row
+    static constexpr int KSTEPS = (DH + 31) / 32;             // MFMA k-steps of Q.K^T
+    static constexpr int NDB = DH / 16;                       // 16-wide output column blocks
+    static constexpr int K_BYTES = KEYS * ROW;
+    static constexpr int V_BYTES = KEYS * ROW;
     static constexpr int LDS_BYTES = K_BYTES + V_BYTES;
     static constexpr int QPW = QB * 16;   // queries per wave
+    __device__ static int k_off(int key, int ch) { return key * ROW + ((DH == 64 ? (ch ^ (key & 7)) : ch) << 4); }
+    __device__ static int v_off(int key, int ch) { return key * ROW + ((DH == 64 ? (ch ^ (((key >> 1) & 3) << 1)) : ch) << 4); }
 };
 
 __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
@@ -42,9 +50,10 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
 
 // PROBS = true: the inspection variant behind the `encoder.layers.<i>.attn` node - same staging, QK^T and
 // softmax, but instead of P.V it writes the normalised probabilities as f32 [B, H, N, N].
-template <int NKF, int QB, bool PROBS>
+template <int DH, int NKF, int QB, bool PROBS>
 __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
-    using L = AttLayout<NKF, QB>;
+    using L = AttLayout<DH, NKF, QB>;
+    constexpr int ATT_DH = DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
     char* v_lds = smem + L::K_BYTES;
@@ -63,26 +72,28 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
 
     // ---- Q fragments of the wave's first query block: issued BEFORE the staging barrier so that their
     // latency overlaps the K/V staging (B operand: lane holds Q[q + fr][kk*32 + 8g .. +7])
-    bf16x8 qf[2];
+    const bf16x8 zero_frag = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 qf[L::KSTEPS];
     {
         const int qrow = min(q0 + fr, N - 1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8);
+        for (int kk = 0; kk < L::KSTEPS; ++kk)
+            qf[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
+                         ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8) : zero_frag;
     }
 
     // ---- stage K and V (row-major, 16-B chunks; rows >= N are zero: 0 * garbage must not be NaN).
     // Batches of 4 chunks per thread: all 8 global loads of a batch are in flight before the first
     // LDS store (a plain loop serialised load -> wait -> store per chunk).
-    for (int c0 = threadIdx.x; c0 < L::KEYS * 8; c0 += 4 * blockDim.x) {
+    for (int c0 = threadIdx.x; c0 < L::KEYS * L::CHUNKS; c0 += 4 * blockDim.x) {
         u32x4 kv[4], vv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = c0 + i * blockDim.x;
-            const int key = c >> 3, ch = c & 7;
+            const int key = c / L::CHUNKS, ch = c % L::CHUNKS;
             kv[i] = u32x4{0u, 0u, 0u, 0u};
             vv[i] = u32x4{0u, 0u, 0u, 0u};
-            if (c < L::KEYS * 8 && key < N) {
+            if (c < L::KEYS * L::CHUNKS && key < N) {
                 const bf16_t* src = qkv + (row0 + key) * ld + h * ATT_DH + ch * 8;
                 kv[i] = *reinterpret_cast<const u32x4*>(src + D);
                 vv[i] = *reinterpret_cast<const u32x4*>(src + 2 * D);
@@ -91,10 +102,10 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = c0 + i * blockDim.x;
-            const int key = c >> 3, ch = c & 7;
-            if (c < L::KEYS * 8) {
-                *reinterpret_cast<u32x4*>(k_lds + key * 128 + ((ch ^ (key & 7)) << 4)) = kv[i];
-                *reinterpret_cast<u32x4*>(v_lds + key * 128 + ((ch ^ (((key >> 1) & 3) << 1)) << 4)) = vv[i];
+            const int key = c / L::CHUNKS, ch = c % L::CHUNKS;
+            if (c < L::KEYS * L::CHUNKS) {
+                *reinterpret_cast<u32x4*>(k_lds + L::k_off(key, ch)) = kv[i];
+                *reinterpret_cast<u32x4*>(v_lds + L::v_off(key, ch)) = vv[i];
             }
         }
     }
@@ -116,8 +127,9 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
         if (c > 0) {   // later blocks: plain load (the first block's fragments were prefetched above)
             const int qrow = min(qbase + fr, N - 1);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8);
+            for (int kk = 0; kk < L::KSTEPS; ++kk)
+                qf[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
+                             ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8) : zero_frag;
         }
 
         // ---- S^T = K Q^T
@@ -127,8 +139,12 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
             const int key = f * 16 + fr;
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + key * 128 + (((kk * 4 + g) ^ (key & 7)) << 4));
+            for (int kk = 0; kk < L::KSTEPS; ++kk) {
+                // every lane reads (EXEC stays full); chunks past the head dim read the next row's
+                // bytes or the pad and are replaced by zeros
+                const int ch = kk * 4 + g;
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + L::k_off(key, ch < L::CHUNKS ? ch : 0));
+                if (ch >= L::CHUNKS) kf = zero_frag;
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], a, 0, 0, 0);
             }
             s[f] = a;
@@ -175,9 +191,9 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
         }
 
         // ---- O^T = V^T P^T
-        f32x4 o[4];
+        f32x4 o[L::NDB];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < L::NDB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < NKF / 2; ++st) {
             const f32x4 p0 = s[2 * st], p1 = s[2 * st + 1];
@@ -187,12 +203,11 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
             pk.u[2] = pack_bf16x2(p1[0], p1[1]);
             pk.u[3] = pack_bf16x2(p1[2], p1[3]);
             const int key_lo = 32 * st + 4 * g + tq;       // first half of the k-slots; second half = +16 keys
-            const int sw_lo = ((key_lo >> 1) & 3) << 1, sw_hi = (((key_lo + 16) >> 1) & 3) << 1;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
+            for (int d = 0; d < L::NDB; ++d) {
                 const int chunk = d * 2 + (tp >> 1);       // 16-B chunk of columns d*16 + 4*tp
-                const char* lo = v_lds + key_lo * 128 + ((chunk ^ sw_lo) << 4) + (tp & 1) * 8;
-                const char* hi = v_lds + (key_lo + 16) * 128 + ((chunk ^ sw_hi) << 4) + (tp & 1) * 8;
+                const char* lo = v_lds + L::v_off(key_lo, chunk) + (tp & 1) * 8;
+                const char* hi = v_lds + L::v_off(key_lo + 16, chunk) + (tp & 1) * 8;
                 union { bf16x8 v; bf16x4 h2[2]; } vf;
                 vf.h2[0] = lds_read_tr16(lo);
                 vf.h2[1] = lds_read_tr16(hi);
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
         if (q < N) {
             bf16_t* orow = p.out + (row0 + q) * p.ldo + h * ATT_DH + g * 4;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
+            for (int d = 0; d < L::NDB; ++d) {
                 u32x2 pk2 = {pack_bf16x2(o[d][0] * inv, o[d][1] * inv), pack_bf16x2(o[d][2] * inv, o[d][3] * inv)};
                 *reinterpret_cast<u32x2*>(orow + d * 16) = pk2;
             }
@@ -215,14 +230,19 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     }
 }
 
-bool attention_supported(int tokens, int head_dim) { return head_dim == ATT_DH && tokens >= 1 && tokens <= 38 * 16; }
+bool attention_supported(int tokens, int head_dim) {
+    if (tokens < 1) return false;
+    if (head_dim == 64) return tokens <= 38 * 16;
+    if (head_dim == 80) return tokens <= 26 * 16;   // 176-B rows: 26 fragments = 143 KiB of LDS
+    return false;
+}
 
-template <int NKF, int QB, bool PROBS>
+template <int DH, int NKF, int QB, bool PROBS>
 static hipError_t launch_nkf_impl(const AttnParams& p, hipStream_t stream) {
-    using L = AttLayout<NKF, QB>;
+    using L = AttLayout<DH, NKF, QB>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<NKF, QB, PROBS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<DH, NKF, QB, PROBS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -230,26 +250,32 @@ static hipError_t launch_nkf_impl(const AttnParams& p, hipStream_t stream) {
     const int waves_needed = ceil_div(p.tokens, L::QPW);
     const int wpb = waves_needed < 8 ? waves_needed : 8;          // waves per workgroup
     dim3 grid(ceil_div(waves_needed, wpb), p.heads, p.batch);
-    hipLaunchKernelGGL((ivit_attention_bf16<NKF, QB, PROBS>), grid, dim3(wpb * 64), L::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, QB, PROBS>), grid, dim3(wpb * 64), L::LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 
-template <int NKF, int QB>
+template <int DH, int NKF, int QB>
 static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
-    return p.probs ? launch_nkf_impl<NKF, QB, true>(p, stream) : launch_nkf_impl<NKF, QB, false>(p, stream);
+    return p.probs ? launch_nkf_impl<DH, NKF, QB, true>(p, stream) : launch_nkf_impl<DH, NKF, QB, false>(p, stream);
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (!attention_supported(p.tokens, p.head_dim)) return hipErrorInvalidValue;
     if ((p.ldqkv % 8) || (!p.probs && (p.ldo % 4))) return hipErrorInvalidValue;
     const int nkf = round_up(ceil_div(p.tokens, 16), 2);
-    if (nkf <= 2) return launch_nkf<2, 2>(p, stream);
-    if (nkf <= 4) return launch_nkf<4, 2>(p, stream);
-    if (nkf <= 8) return launch_nkf<8, 2>(p, stream);
-    if (nkf <= 14) return launch_nkf<14, 2>(p, stream);   // 197 tokens (224^2 / 16): 7 waves x 32 queries
-    if (nkf <= 18) return launch_nkf<18, 2>(p, stream);   // 257 tokens (224^2 / 14)
-    if (nkf <= 26) return launch_nkf<26, 1>(p, stream);
-    return launch_nkf<38, 1>(p, stream);                  // 577 tokens (384^2 / 16): 16 queries per wave
+    if (p.head_dim == 80) {
+        if (nkf <= 2) return launch_nkf<80, 2, 2>(p, stream);
+        if (nkf <= 8) return launch_nkf<80, 8, 2>(p, stream);
+        if (nkf <= 18) return launch_nkf<80, 18, 2>(p, stream);   // ViT-H/14: 257 tokens
+        return launch_nkf<80, 26, 1>(p, stream);
+    }
+    if (nkf <= 2) return launch_nkf<64, 2, 2>(p, stream);
+    if (nkf <= 4) return launch_nkf<64, 4, 2>(p, stream);
+    if (nkf <= 8) return launch_nkf<64, 8, 2>(p, stream);
+    if (nkf <= 14) return launch_nkf<64, 14, 2>(p, stream);   // 197 tokens (224^2 / 16): 7 waves x 32 queries
+    if (nkf <= 18) return launch_nkf<64, 18, 2>(p, stream);   // 257 tokens (224^2 / 14)
+    if (nkf <= 26) return launch_nkf<64, 26, 1>(p, stream);
+    return launch_nkf<64, 38, 1>(p, stream);                  // 577 tokens (384^2 / 16): 16 queries per wave
 }
 
 }  // namespace ivit

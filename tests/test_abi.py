@@ -85,7 +85,8 @@ def test_bad_configs_are_rejected_with_messages(built_lib):
     lib = engine.load_library()
     h = ctypes.c_void_p()
     for field, value, text in (("image", 230, "multiple of patch"), ("dim", 100, "multiple of 64"),
-                               ("heads", 5, "divisible by heads"), ("max_batch", 0, "max_batch")):
+                               ("heads", 5, "divisible by heads"), ("max_batch", 0, "max_batch"),
+                               ("heads", 1, "head_dim")):
         cfg = small_config()
         c = engine._config_c(cfg, 0, 1)
         setattr(c, field, value)
