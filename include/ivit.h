@@ -39,7 +39,10 @@
 extern "C" {
 #endif
 
-#define IVIT_ABI_VERSION 1
+#define IVIT_ABI_VERSION 2
+
+#define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
+#define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
 
 typedef struct ivit_engine ivit_engine;
 
@@ -54,6 +57,7 @@ typedef struct ivit_config {
     float   ln_eps;
     int32_t device;     /* HIP device ordinal */
     int32_t max_batch;  /* workspaces are sized for this many images per call */
+    int32_t precision;  /* IVIT_PRECISION_* */
 } ivit_config;
 
 /* ABI / build introspection (no GPU needed). */
@@ -103,6 +107,16 @@ int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_end, int batc
 int ivit_attention_map(ivit_engine* e, int layer, int batch, const void* in, void* out, void* stream);
 /* host-buffer form of the same (CPU f32 in / out; out_capacity in floats) */
 int ivit_attention_map_host(ivit_engine* e, int layer, int batch, const float* in, float* out, int64_t out_capacity);
+
+/* fp8 data path (IVIT_PRECISION_FP8).  Policy (the reference has none - stated in DESIGN.md): OCP e4m3fn,
+ * saturating; weights quantised per OUTPUT ROW (scale = row amax / 448) from their bf16 copies;
+ * activations feeding the four encoder GEMMs of every layer (LN1 out, attention out, LN2 out, GELU
+ * out) quantised per TENSOR with static scales = amax / 448 measured by one bf16 calibration forward
+ * of `batch` images (`in`: device f32 [B,3,S,S] in [0,1]).  Patch embedding and classifier head stay
+ * bf16; accumulation, LN/softmax statistics and the residual stream stay f32; q|k|v stay bf16.
+ * ivit_fp8_scales copies the L*4 activation scales (layer-major: h1, att, h2, u) to host memory. */
+int ivit_fp8_calibrate(ivit_engine* e, int batch, const void* in, void* stream);
+int ivit_fp8_scales(ivit_engine* e, float* out, int capacity);
 
 /* Inspection entry used by the parity tests: the bf16 unfold image [B*Np, Kpad] the patch GEMM
  * consumes, widened to f32 into `out` (device, B*Np*K floats, padding columns dropped).

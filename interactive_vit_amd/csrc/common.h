@@ -38,6 +38,18 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, r);
 }
 
+// fp8 (OCP e4m3fn on gfx950): two f32 -> two fp8 bytes, round to nearest even, SATURATING at +-448
+// (clamped here in software: torch's cast gives NaN above 448 and the oracle clamps the same way).
+constexpr float FP8_MAX = 448.0f;
+__device__ __forceinline__ unsigned int pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -FP8_MAX), FP8_MAX); b = fminf(fmaxf(b, -FP8_MAX), FP8_MAX);
+    c = fminf(fmaxf(c, -FP8_MAX), FP8_MAX); d = fminf(fmaxf(d, -FP8_MAX), FP8_MAX);
+    int p = 0;
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, p, false);   // bytes 0,1
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);    // bytes 2,3
+    return (unsigned int)p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -39,7 +39,7 @@ static int fail(const char* fmt, ...) {
 extern "C" const char* ivit_last_error(void) { return t_last_error.c_str(); }
 extern "C" int ivit_abi_version(void) { return IVIT_ABI_VERSION; }
 extern "C" const char* ivit_build_info(void) {
-    return "libivit gfx950 (MI355X/CDNA4) bf16-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_{128x128,160x128,256x256}x64, ivit_attention_bf16, "
+    return "libivit gfx950 (MI355X/CDNA4) bf16/fp8-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_{128x128,160x128,256x256}x64, ivit_gemm_fp8_{128x128,160x128}x128, ivit_attention_bf16, "
            "ivit_layernorm, ivit_unfold, ivit_tokens, ivit_transform";
 }
 
@@ -56,6 +56,7 @@ static bool config_ok(const ivit_config* c, std::string* why) {
     if (c->mlp <= 0 || c->mlp % 64) return bad("mlp must be a positive multiple of 64");
     if (c->layers < 0 || c->classes <= 0 || c->max_batch <= 0) return bad("layers/classes/max_batch out of range");
     if (c->dim > 2048) return bad("dim > 2048 unsupported");
+    if (c->precision != IVIT_PRECISION_BF16 && c->precision != IVIT_PRECISION_FP8) return bad("precision must be IVIT_PRECISION_BF16 or IVIT_PRECISION_FP8");
     return true;
 }
 
@@ -96,10 +97,18 @@ struct Matrix {   // bf16 [rows_pad][ld], zero padded
     bf16_t* p = nullptr;
     int rows = 0, cols = 0, ld = 0;
 };
+struct Matrix8 {  // e4m3 [rows_pad][ld] (ld = round_up(cols, 128) bytes), zero padded, + per-row scales
+    unsigned char* p = nullptr;
+    float* rowscale = nullptr;   // [rows]
+    float* colscale = nullptr;   // [rows]: activation scale x rowscale, what the GEMM epilogue multiplies by
+    int rows = 0, cols = 0, ld = 0;
+};
 struct LayerWeights {
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
     float *b_in = nullptr, *b_out = nullptr, *b1 = nullptr, *b2 = nullptr;
     Matrix w_in, w_out, w1, w2;
+    Matrix8 q_in, q_out, q1, q2;                    // fp8 data path only
+    float s_h1 = 1.f, s_att = 1.f, s_h2 = 1.f, s_u = 1.f;   // static activation scales (calibrated)
 };
 
 // Row-offset view of the activation workspaces: the whole batch, or one of the sub-batches that
@@ -107,6 +116,7 @@ struct LayerWeights {
 struct Ws {
     bf16_t *patches, *h, *qkv, *att, *u, *hc;
     float *x, *clsf;
+    unsigned char *h8, *att8, *u8;   // fp8 data path only
 };
 
 struct ivit_engine {
@@ -134,6 +144,10 @@ struct ivit_engine {
 
     // workspaces (row counts padded so that tile loads never leave the allocation)
     bf16_t *patches = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *u = nullptr, *hc = nullptr;
+    unsigned char *h8 = nullptr, *att8 = nullptr, *u8 = nullptr;   // fp8 activations [rows][ld8d / ld8m]
+    int ld8d = 0, ld8m = 0;
+    float* amax_dev = nullptr;      // [L*4] calibration maxima
+    bool fp8_ready = false;
     float *x = nullptr, *clsf = nullptr, *ext_in = nullptr, *ext_out = nullptr, *upload = nullptr;
     int64_t ext_elems = 0, upload_elems = 0;
     float* map_buf = nullptr;     // attention-map staging for the host path (grown on demand)
@@ -259,6 +273,20 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     chk(dev_alloc(e, (void**)&e->att, (size_t)rows_tok * D * 2, true));
     chk(dev_alloc(e, (void**)&e->u, (size_t)rows_tok * Mlp * 2, true));
     chk(dev_alloc(e, (void**)&e->hc, (size_t)(round_up(B, 256) + 256) * D * 2, true));
+    if (cfg->precision == IVIT_PRECISION_FP8) {
+        e->ld8d = round_up(D, 128); e->ld8m = round_up(Mlp, 128);
+        chk(dev_alloc(e, (void**)&e->h8, (size_t)rows_tok * e->ld8d, true));
+        chk(dev_alloc(e, (void**)&e->att8, (size_t)rows_tok * e->ld8d, true));
+        chk(dev_alloc(e, (void**)&e->u8, (size_t)rows_tok * e->ld8m, true));
+        chk(alloc_vec(e, &e->amax_dev, (int64_t)cfg->layers * 4 + 4));
+        auto alloc8 = [&](Matrix8* q, int rows, int cols) {
+            q->rows = rows; q->cols = cols; q->ld = round_up(cols, 128);
+            chk(dev_alloc(e, (void**)&q->p, (size_t)round_up(rows, 256) * q->ld, true));
+            chk(alloc_vec(e, &q->rowscale, rows));
+            chk(alloc_vec(e, &q->colscale, rows));
+        };
+        for (auto& lw : e->layers) { alloc8(&lw.q_in, 3 * D, D); alloc8(&lw.q_out, D, D); alloc8(&lw.q1, Mlp, D); alloc8(&lw.q2, D, Mlp); }
+    }
     chk(alloc_vec(e, &e->clsf, (int64_t)B * D));
     int64_t per_img = 0;
     for (int s = 0; s < 6 + cfg->layers; ++s)
@@ -364,6 +392,7 @@ extern "C" int ivit_set_weight(ivit_engine* e, const char* name, const float* ho
         HIP_TRY(hipStreamSynchronize(e->own_stream));
     }
     e->have[name] = true;
+    e->fp8_ready = false;          // quantised copies are rebuilt by the next ivit_fp8_calibrate
     e->weights_complete = false;   // re-evaluated lazily by the next forward / ivit_weights_ready
     return 0;
 }
@@ -400,31 +429,75 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
 }
 
 static int run_layernorm(ivit_engine* e, hipStream_t st, const float* x, int64_t row_stride, int rows, const float* g,
-                         const float* b, bf16_t* o16, float* o32) {
+                         const float* b, bf16_t* o16, float* o32, unsigned char* o8 = nullptr, float scale8 = 1.0f) {
     const int D = e->D;
-    ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)rows * D * (4.0 + (o16 ? 2.0 : 0.0) + (o32 ? 4.0 : 0.0)));
-    HIP_TRY(launch_layernorm(x, D, row_stride, rows, D, g, b, e->cfg.ln_eps, o16, D, o32, D, st));
+    ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)rows * D * (4.0 + (o16 ? 2.0 : 0.0) + (o32 ? 4.0 : 0.0) + (o8 ? 1.0 : 0.0)));
+    HIP_TRY(launch_layernorm(x, D, row_stride, rows, D, g, b, e->cfg.ln_eps, o16, D, o32, D, st, o8, e->ld8d, scale8));
     return 0;
 }
 
-static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B) {
+// fp8 operands: A [M, ld8] bytes, W = quantised matrix; epilogue dequantises with q.colscale
+static int run_gemm_fp8(ivit_engine* e, hipStream_t st, const unsigned char* A, int lda, const Matrix8& q, int M, const float* bias,
+                        int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, float out_scale = 1.0f) {
+    GemmParams p{};
+    p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(q.p); p.ldw = q.ld;
+    p.M = M; p.N = q.rows; p.K = q.ld; p.colscale = q.colscale; p.out_scale = out_scale;
+    p.bias = bias; p.epi = epi; p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr;
+    const double flops = 2.0 * M * (double)q.rows * q.cols;
+    const double out_b = (epi == EPI_BIAS_GELU_FP8) ? 1.0 : (epi == EPI_BIAS_BF16 ? 2.0 : 4.0);
+    const double bytes = ((double)M * q.cols + (double)q.rows * q.cols) + (double)M * q.rows * out_b +
+                         (epi == EPI_BIAS_RESID_F32 ? 4.0 * M * q.rows : 0.0);
+    ProfScope ps(e, PC_GEMM, st, flops, bytes);
+    HIP_TRY(launch_gemm_fp8(p, st));
+    return 0;
+}
+
+static int run_attention(ivit_engine* e, const Ws& w, hipStream_t st, int B, unsigned char* out8, float scale8) {
+    const int D = e->D, M = B * e->N;
+    AttnParams ap{};
+    ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = D;
+    ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh;
+    ap.scale = 1.0f / std::sqrt((float)e->dh);
+    ap.probs = nullptr;
+    ap.out8 = out8; ap.ldo8 = e->ld8d; ap.scale8 = scale8;
+    const double flops = 4.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh;
+    ProfScope ps(e, PC_ATTN, st, flops, 2.0 * M * 3.0 * D + (out8 ? 1.0 : 2.0) * M * D);
+    HIP_TRY(launch_attention(ap, st));
+    return 0;
+}
+
+// fp8 data path of one encoder layer (IVIT_PRECISION_FP8, after calibration)
+static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B) {
+    const int D = e->D, M = B * e->N;
+    LayerWeights& lw = e->layers[li];
+    if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, nullptr, nullptr, w.h8, 1.0f / lw.s_h1)) return 1;
+    if (run_gemm_fp8(e, st, w.h8, e->ld8d, lw.q_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
+    if (run_attention(e, w, st, B, w.att8, 1.0f / lw.s_att)) return 1;
+    if (run_gemm_fp8(e, st, w.att8, e->ld8d, lw.q_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
+    if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, nullptr, nullptr, w.h8, 1.0f / lw.s_h2)) return 1;
+    if (run_gemm_fp8(e, st, w.h8, e->ld8d, lw.q1, M, lw.b1, EPI_BIAS_GELU_FP8, w.u8, e->ld8m, nullptr, 0, 1.0f / lw.s_u)) return 1;
+    if (run_gemm_fp8(e, st, w.u8, e->ld8m, lw.q2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
+    return 0;
+}
+
+// bf16 layer; amax4 != nullptr (calibration): record max|.| of the four GEMM-input tensors
+static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B, float* amax4 = nullptr) {
     const int D = e->D, M = B * e->N, Mlp = e->cfg.mlp;
     LayerWeights& lw = e->layers[li];
-    if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
-    if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
-    {
-        AttnParams ap{};
-        ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = D;
-        ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh;
-        ap.scale = 1.0f / std::sqrt((float)e->dh);
-        ap.probs = nullptr;
-        const double flops = 4.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh;
-        ProfScope ps(e, PC_ATTN, st, flops, 2.0 * M * 4.0 * D);
-        HIP_TRY(launch_attention(ap, st));
+    if (!amax4 && e->cfg.precision == IVIT_PRECISION_FP8) {
+        if (!e->fp8_ready) return fail("fp8 engine is not calibrated: call ivit_fp8_calibrate first");
+        return run_layer_fp8(e, w, st, li, B);
     }
+    if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
+    if (amax4) HIP_TRY(launch_amax_bf16(w.h, D, M, D, amax4 + 0, st));
+    if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
+    if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
+    if (amax4) HIP_TRY(launch_amax_bf16(w.att, D, M, D, amax4 + 1, st));
     if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
     if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, w.h, nullptr)) return 1;
+    if (amax4) HIP_TRY(launch_amax_bf16(w.h, D, M, D, amax4 + 2, st));
     if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp)) return 1;
+    if (amax4) HIP_TRY(launch_amax_bf16(w.u, Mlp, M, Mlp, amax4 + 3, st));
     if (run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
     return 0;
 }
@@ -552,6 +625,9 @@ static Ws ws_slice(ivit_engine* e, int b0) {
     w.u = e->u + rt * e->cfg.mlp;
     w.hc = e->hc + (size_t)b0 * e->D;
     w.clsf = e->clsf + (size_t)b0 * e->D;
+    w.h8 = e->h8 ? e->h8 + rt * e->ld8d : nullptr;
+    w.att8 = e->att8 ? e->att8 + rt * e->ld8d : nullptr;
+    w.u8 = e->u8 ? e->u8 + rt * e->ld8m : nullptr;
     return w;
 }
 
@@ -651,6 +727,7 @@ static int attention_map_locked(ivit_engine* e, int layer, int B, const float* i
     ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh;
     ap.scale = 1.0f / std::sqrt((float)e->dh);
     ap.probs = out;
+    ap.out8 = nullptr; ap.ldo8 = 0; ap.scale8 = 1.0f;
     ProfScope ps(e, PC_ATTN, st, 2.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh, 0.0);
     HIP_TRY(launch_attention(ap, st));
     return 0;
@@ -691,6 +768,59 @@ extern "C" int ivit_attention_map_host(ivit_engine* e, int layer, int batch, con
     HIP_TRY(hipMemcpyAsync(out, e->map_buf, need, hipMemcpyDeviceToHost, st));
     if (ws_release(e, st)) return 1;
     HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int ivit_fp8_calibrate(ivit_engine* e, int batch, const void* in, void* stream) {
+    if (!e || !in) return fail("ivit_fp8_calibrate: null argument");
+    if (e->cfg.precision != IVIT_PRECISION_FP8) return fail("ivit_fp8_calibrate: engine was created with IVIT_PRECISION_BF16");
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (require_weights(e)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int L = e->cfg.layers, D = e->D, Mlp = e->cfg.mlp;
+    if (ws_acquire(e, st)) return 1;
+    // 1. one bf16 forward of the calibration batch, recording max|.| of every fp8-bound tensor
+    HIP_TRY(hipMemsetAsync(e->amax_dev, 0, (size_t)(L * 4 + 4) * sizeof(float), st));
+    const Ws w = ws_slice(e, 0);
+    if (forward_one(e, w, ST_TRANSFORM, ST_LAYER0, batch, (const float*)in, w.x, nullptr, st)) return 1;   // -> residual stream in w.x
+    for (int li = 0; li < L; ++li)
+        if (run_layer(e, w, st, li, batch, e->amax_dev + 4 * li)) return 1;
+    std::vector<float> amax((size_t)L * 4);
+    HIP_TRY(hipMemcpyAsync(amax.data(), e->amax_dev, amax.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // 2. static activation scales, per-row weight quantisation, combined dequantisation vectors
+    for (int li = 0; li < L; ++li) {
+        LayerWeights& lw = e->layers[li];
+        auto sc = [&](float a) { return (a > 0.f && std::isfinite(a)) ? a / 448.0f : 1.0f; };
+        lw.s_h1 = sc(amax[4 * li + 0]); lw.s_att = sc(amax[4 * li + 1]); lw.s_h2 = sc(amax[4 * li + 2]); lw.s_u = sc(amax[4 * li + 3]);
+        struct { const Matrix* w; Matrix8* q; float sa; } jobs[4] = {
+            {&lw.w_in, &lw.q_in, lw.s_h1}, {&lw.w_out, &lw.q_out, lw.s_att}, {&lw.w1, &lw.q1, lw.s_h2}, {&lw.w2, &lw.q2, lw.s_u}};
+        for (auto& j : jobs) {
+            HIP_TRY(launch_quantize_weight_fp8(j.w->p, j.w->ld, j.w->rows, j.w->cols, j.q->p, j.q->ld, j.q->rowscale, st));
+            HIP_TRY(launch_scale_vec(j.q->rowscale, j.sa, j.q->colscale, j.q->rows, st));
+        }
+    }
+    (void)D; (void)Mlp;
+    if (ws_release(e, st)) return 1;
+    HIP_TRY(hipStreamSynchronize(st));
+    e->fp8_ready = true;
+    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);   // captured launches embed the old scales
+    e->graphs.clear();
+    return 0;
+}
+
+extern "C" int ivit_fp8_scales(ivit_engine* e, float* out, int capacity) {
+    if (!e || !out) return fail("ivit_fp8_scales: null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->fp8_ready) return fail("fp8 engine is not calibrated: call ivit_fp8_calibrate first");
+    const int L = e->cfg.layers;
+    if (capacity < 4 * L) return fail("ivit_fp8_scales: need room for %d floats", 4 * L);
+    for (int li = 0; li < L; ++li) {
+        const LayerWeights& lw = e->layers[li];
+        out[4 * li + 0] = lw.s_h1; out[4 * li + 1] = lw.s_att; out[4 * li + 2] = lw.s_h2; out[4 * li + 3] = lw.s_u;
+    }
     return 0;
 }
 

@@ -39,17 +39,18 @@ struct GemmTile {
 
 // Issue the global->LDS copies of one ROWS x 64 bf16 tile: each wave-instruction covers 8 rows x
 // 128 B.  LDS slot (row r, chunk c) receives global chunk c ^ (r & 7).
+// (byte addressing: the same code stages bf16 tiles of 64 k and fp8 tiles of 128 k - both 128-B rows)
 template <int PIECES, int WAVES>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int k0,
+__device__ __forceinline__ void stage_tile(const void* __restrict__ g, size_t ld_bytes, int row0, int k0_bytes,
                                            char* lds_tile, int wave, int lane) {
     const int r_in = lane >> 3;            // row inside the 8-row piece
     const int chunk = (lane & 7) ^ r_in;   // (r_local & 7) == r_in because pieces are 8-row aligned
-    const bf16_t* src = g + (size_t)(row0 + r_in) * ld + k0 + chunk * 8;
+    const char* src = reinterpret_cast<const char*>(g) + (size_t)(row0 + r_in) * ld_bytes + k0_bytes + chunk * 16;
 #pragma unroll
     for (int i = 0; i < (PIECES + WAVES - 1) / WAVES; ++i) {
         const int piece = i * WAVES + wave;
         if (PIECES % WAVES == 0 || piece < PIECES)
-            __builtin_amdgcn_global_load_lds((const IVIT_GLOBAL void*)(src + (size_t)piece * 8 * ld),
+            __builtin_amdgcn_global_load_lds((const IVIT_GLOBAL void*)(src + (size_t)piece * 8 * ld_bytes),
                                              (IVIT_LDS void*)(lds_tile + piece * 1024), 16, 0, 0);
     }
 }
@@ -79,6 +80,16 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
             float b[4] = {0.f, 0.f, 0.f, 0.f};
             for (int r = 0; r < 4; ++r) if (n + r < p.N) b[r] = p.bias[n + r];
             bias4[j] = make_float4(b[0], b[1], b[2], b[3]);
+        }
+    }
+    if (p.colscale) {   // fp8 operands: dequantise the accumulators (wave-uniform branch, once per tile)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) {
+            const int n = n_base + j * 16 + fq * 4;
+            float c[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) if (INTERIOR || n + r < p.N) c[r] = p.colscale[n + r];
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i) { acc[i][j][0] *= c[0]; acc[i][j][1] *= c[1]; acc[i][j][2] *= c[2]; acc[i][j][3] *= c[3]; }
         }
     }
 #pragma unroll
@@ -129,11 +140,16 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
             if (!INTERIOR && n >= p.N) continue;
             float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
             const bool full = INTERIOR || (n + 3 < p.N);
-            if (epi == EPI_BIAS_GELU_BF16) {
+            if (epi == EPI_BIAS_GELU_BF16 || epi == EPI_BIAS_GELU_FP8) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
             }
-            if (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16) {
+            if (epi == EPI_BIAS_GELU_FP8) {   // 4 consecutive n -> one dword of e4m3
+                unsigned char* o = reinterpret_cast<unsigned char*>(p.out) + (size_t)orow * p.ldo + n;
+                const unsigned int pk = pack_fp8x4(v[0] * p.out_scale, v[1] * p.out_scale, v[2] * p.out_scale, v[3] * p.out_scale);
+                if (full) *reinterpret_cast<unsigned int*>(o) = pk;
+                else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = (unsigned char)(pk >> (8 * r));
+            } else if (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16) {
                 bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + n;
                 if (full) {
                     u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -205,7 +221,7 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, 
     tn = panel * GEMM_GROUP_N + (within - tm * width);
 }
 
-template <class T>
+template <class T, bool FP8 = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -222,9 +238,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
 #pragma unroll
         for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = p.K / GEMM_BK;
-    stage_tile<T::A_PIECES, T::WAVES>(p.A, p.lda, m0, 0, smem, wave, lane);
-    stage_tile<T::W_PIECES, T::WAVES>(p.W, p.ldw, n0, 0, smem + T::A_BYTES, wave, lane);
+    // a K-tile is 128 BYTES of every row: 64 bf16 or 128 fp8
+    constexpr int ESZ = FP8 ? 1 : 2;
+    const size_t lda_b = (size_t)p.lda * ESZ, ldw_b = (size_t)p.ldw * ESZ;
+    const int nt = p.K * ESZ / 128;
+    stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, 0, smem, wave, lane);
+    stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, 0, smem + T::A_BYTES, wave, lane);
 
     const int fr = lane & 15;   // fragment row (m for the A^T operand, n for the W operand)
     const int fq = lane >> 4;   // 16-B k-chunk inside a 32-deep MFMA step
@@ -237,8 +256,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
         char* cur = smem + (t & 1) * T::STAGE_BYTES;
         if (t + 1 < nt) {
             char* nxt = smem + ((t + 1) & 1) * T::STAGE_BYTES;
-            stage_tile<T::A_PIECES, T::WAVES>(p.A, p.lda, m0, (t + 1) * GEMM_BK, nxt, wave, lane);
-            stage_tile<T::W_PIECES, T::WAVES>(p.W, p.ldw, n0, (t + 1) * GEMM_BK, nxt + T::A_BYTES, wave, lane);
+            stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, (t + 1) * 128, nxt, wave, lane);
+            stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, (t + 1) * 128, nxt + T::A_BYTES, wave, lane);
         }
         const char* a_tile = cur;
         const char* w_tile = cur + T::A_BYTES;
@@ -250,11 +269,25 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
 #pragma unroll
             for (int i = 0; i < T::FM; ++i) af[i] = read_frag(a_tile, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
             __builtin_amdgcn_s_setprio(1);
+            if (FP8) {
+                // a 16-B fragment holds 16 consecutive fp8 k: its two 8-B halves are the operands of two
+                // 32-deep MFMA steps (both operands are cut the same way, so the k pairing is consistent)
+                typedef __attribute__((ext_vector_type(2))) long l64x2;
 #pragma unroll
-            for (int i = 0; i < T::FM; ++i)
+                for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int j = 0; j < T::FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < T::FN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(l64x2, wf[j])[hf],
+                                                                                   __builtin_bit_cast(l64x2, af[i])[hf], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
         }
     }

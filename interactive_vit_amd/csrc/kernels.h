@@ -11,12 +11,15 @@ enum GemmEpilogue : int {
     EPI_BIAS_RESID_F32 = 2,  // out(f32)   = resid + (acc + bias)          (out may alias resid)
     EPI_BIAS_F32 = 3,        // out(f32)   = acc + bias
     EPI_BIAS_ROWADD_F32 = 4, // out(f32)[remap(m)] = (acc + bias) + rowadd[grp_off + m % grp_in]
+    EPI_BIAS_GELU_FP8 = 5,   // out(fp8)  = sat_fp8(gelu_erf(acc + bias) * out_scale)
 };
 
 struct GemmParams {
     const bf16_t* A; int lda;     // [M, K] bf16 row-major, rows readable up to round_up(M,256)+256
     const bf16_t* W; int ldw;     // [N, K] bf16 row-major, rows readable up to round_up(N,256)
-    int M, N, K;                  // K % 64 == 0 (operands zero-padded)
+    int M, N, K;                  // K % 64 == 0 (operands zero-padded); fp8 operands: K % 128 == 0
+    const float* colscale;        // fp8 operands: acc *= colscale[n] (= activation scale x weight-row scale) before the bias
+    float out_scale;              // EPI_BIAS_GELU_FP8: 1 / (scale of the fp8 output tensor)
     const float* bias;            // [N]
     int epi;
     void* out; int ldo;
@@ -28,6 +31,8 @@ struct GemmParams {
 };
 
 enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_VARIANTS = 6 };
+// fp8 (e4m3) operands, f32 accumulate: A [M,K] and W [N,K] are BYTE matrices (lda/ldw in elements = bytes)
+hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream);
 // Operand allocations must be readable up to the tile edge: A rows up to round_up(M,256)+256,
 // W rows up to round_up(N,256) (engine.hip pads every buffer accordingly).
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);                       // picks the tile
@@ -42,6 +47,8 @@ struct AttnParams {
     int batch, tokens, heads, head_dim;
     float scale;                   // 1/sqrt(dh)
     float* probs;                  // nullptr, or f32 [B, H, N, N]: write the attention probabilities instead of P.V
+    unsigned char* out8; int ldo8; // nullptr, or e4m3 [B*N, D]: write sat_fp8(O * scale8) INSTEAD of the bf16 output
+    float scale8;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 bool attention_supported(int tokens, int head_dim);
@@ -57,9 +64,15 @@ hipError_t launch_tokens(const float* in, const float* cls, const float* pos, fl
                          int patches, int dim, hipStream_t s);
 // LayerNorm over the last dim of rows `row0 + i*row_stride` (i < rows) of a [*, dim] f32 matrix;
 // writes bf16 (out_bf16, ld = ldo16) and/or f32 (out_f32, ld = ldo32) at row i.
+// optional third output: e4m3 (out_fp8, ld = ldo8 bytes) = sat_fp8(y * scale8)
 hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, bf16_t* out_bf16, int ldo16, float* out_f32,
-                            int ldo32, hipStream_t s);
+                            int ldo32, hipStream_t s, unsigned char* out_fp8 = nullptr, int ldo8 = 0, float scale8 = 1.0f);
+// fp8 support: tensor amax (atomicMax into *out, which the caller zeroes), per-row weight quantisation, vector scale
+hipError_t launch_amax_bf16(const bf16_t* in, int ld, int rows, int cols, float* out, hipStream_t s);
+hipError_t launch_quantize_weight_fp8(const bf16_t* w, int ld, int rows, int cols, unsigned char* w8, int ld8, float* rowscale,
+                                      hipStream_t s);
+hipError_t launch_scale_vec(const float* in, float a, float* out, int n, hipStream_t s);
 // strided row gather: out[i,:] = in[i*row_stride, :dim]  (the `cls` node)
 hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, int rows, int dim, hipStream_t s);
 // f32 [rows, cols] -> bf16 [rows, ldo] (columns >= cols zero)

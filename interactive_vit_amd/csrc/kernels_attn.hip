@@ -219,7 +219,13 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
         // (the guard diverges only here, after the last transposed read of this block, which needs
         // EXEC all ones; the next block's reads run with the full mask again)
         const int q = qbase + fr;
-        if (q < N) {
+        if (q < N && p.out8) {   // fp8 data path: 4 consecutive d -> one dword of e4m3
+            unsigned char* orow8 = p.out8 + (row0 + q) * p.ldo8 + h * ATT_DH + g * 4;
+            const float sc = inv * p.scale8;
+#pragma unroll
+            for (int d = 0; d < L::NDB; ++d)
+                *reinterpret_cast<unsigned int*>(orow8 + d * 16) = pack_fp8x4(o[d][0] * sc, o[d][1] * sc, o[d][2] * sc, o[d][3] * sc);
+        } else if (q < N) {
             bf16_t* orow = p.out + (row0 + q) * p.ldo + h * ATT_DH + g * 4;
 #pragma unroll
             for (int d = 0; d < L::NDB; ++d) {
@@ -261,7 +267,7 @@ static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (!attention_supported(p.tokens, p.head_dim)) return hipErrorInvalidValue;
-    if ((p.ldqkv % 8) || (!p.probs && (p.ldo % 4))) return hipErrorInvalidValue;
+    if ((p.ldqkv % 8) || (!p.probs && !p.out8 && (p.ldo % 4)) || (p.out8 && (p.ldo8 % 4))) return hipErrorInvalidValue;
     const int nkf = round_up(ceil_div(p.tokens, 16), 2);
     if (p.head_dim == 80) {
         if (nkf <= 2) return launch_nkf<80, 2, 2>(p, stream);

@@ -17,6 +17,15 @@ __global__ __launch_bounds__(Tile160::THREADS, 2) void ivit_gemm_bf16_160x128x64
     gemm_body<Tile160>(p, smem);
 }
 
+// fp8 (e4m3) operands: same tiles, K-tile of 128 elements, two fp8 MFMA steps per 16-B fragment
+__global__ __launch_bounds__(Tile128::THREADS, 2) void ivit_gemm_fp8_128x128x128(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<Tile128, true>(p, smem);
+}
+__global__ __launch_bounds__(Tile160::THREADS, 2) void ivit_gemm_fp8_160x128x128(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_body<Tile160, true>(p, smem);
+}
 __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm256s_body<0>(p, smem);
@@ -159,6 +168,17 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
             return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag, p, stream);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if (p.K <= 0 || p.K % 128 != 0 || !p.colscale) return hipErrorInvalidValue;
+    if ((p.lda % 16) || (p.ldw % 16) || (p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
+    struct Cand { int bm, bn; double speed; };
+    const double t160 = std::ceil((double)ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) / 512.0) * Tile160::BM / 1.03;
+    const double t128 = std::ceil((double)ceil_div(p.M, Tile128::BM) * ceil_div(p.N, Tile128::BN) / 512.0) * Tile128::BM;
+    if (t160 <= t128) return launch_tile<Tile160>(ivit_gemm_fp8_160x128x128, p, stream);
+    return launch_tile<Tile128>(ivit_gemm_fp8_128x128x128, p, stream);
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {

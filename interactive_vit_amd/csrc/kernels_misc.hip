@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
                                                       int dim, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
                                                       bf16_t* __restrict__ o16, int ldo16, float* __restrict__ o32,
-                                                      int ldo32) {
+                                                      int ldo32, unsigned char* __restrict__ o8, int ldo8, float scale8) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
     if (row0 >= rows) return;
@@ -191,6 +191,8 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
                     u32x2 pk = {pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
                     reinterpret_cast<u32x2*>(o16 + (size_t)row * ldo16)[c] = pk;
                 }
+                if (o8)   // e4m3 with the tensor's calibrated scale (scale8 = 1 / scale)
+                    reinterpret_cast<unsigned int*>(o8 + (size_t)row * ldo8)[c] = pack_fp8x4(y.x * scale8, y.y * scale8, y.z * scale8, y.w * scale8);
             }
         }
     }
@@ -198,12 +200,12 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
 
 hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, bf16_t* o16, int ldo16, float* o32, int ldo32,
-                            hipStream_t s) {
+                            hipStream_t s, unsigned char* o8, int ldo8, float scale8) {
     if (dim % 4 || dim > 64 * 4 * 8) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
     const dim3 grid(ceil_div(rows, 4 * LN_RPW)), block(256);
     const int vpl = ceil_div(dim / 4, 64);
-#define IVIT_LN(V) hipLaunchKernelGGL(ivit_layernorm<V>, grid, block, 0, s, x, ldx, row_stride, rows, dim, gamma, beta, eps, o16, ldo16, o32, ldo32)
+#define IVIT_LN(V) hipLaunchKernelGGL(ivit_layernorm<V>, grid, block, 0, s, x, ldx, row_stride, rows, dim, gamma, beta, eps, o16, ldo16, o32, ldo32, o8, ldo8, scale8)
     if (vpl <= 1) IVIT_LN(1);
     else if (vpl <= 2) IVIT_LN(2);
     else if (vpl <= 3) IVIT_LN(3);
@@ -262,6 +264,73 @@ __global__ void ivit_bf16_to_f32(const bf16_t* __restrict__ in, int ldi, float* 
 
 hipError_t launch_bf16_to_f32(const bf16_t* in, int ldi, float* out, int rows, int cols, hipStream_t s) {
     hipLaunchKernelGGL(ivit_bf16_to_f32, dim3(ew_grid((int64_t)rows * cols)), dim3(EW_THREADS), 0, s, in, ldi, out, rows, cols);
+    return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------- fp8 support
+// max |x| over a bf16 [rows, cols] matrix (ld elements) -> atomicMax on the f32 bit pattern (values >= 0)
+__global__ void ivit_amax_bf16(const bf16_t* __restrict__ in, int ld, int rows, int cols, unsigned int* __restrict__ out) {
+    const int c8 = cols >> 3;
+    const int64_t total = (int64_t)rows * c8;
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c8);
+        const int64_t r = i / c8;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(in + r * ld + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m = fmaxf(m, fabsf(bf2f((bf16_t)(v[e] & 0xffffu))));
+            m = fmaxf(m, fabsf(bf2f((bf16_t)(v[e] >> 16))));
+        }
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+hipError_t launch_amax_bf16(const bf16_t* in, int ld, int rows, int cols, float* out, hipStream_t s) {
+    if (cols % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivit_amax_bf16, dim3(ew_grid((int64_t)rows * cols / 8)), dim3(EW_THREADS), 0, s, in, ld, rows, cols,
+                       reinterpret_cast<unsigned int*>(out));
+    return hipGetLastError();
+}
+
+// bf16 weight matrix [rows, cols] (ld) -> e4m3 [rows, ld8] with one scale per output row:
+// rowscale[n] = max_k |W[n,k]| / 448 (1 if the row is all zero); padding columns are written as 0.
+__global__ __launch_bounds__(256) void ivit_quantize_weight_fp8(const bf16_t* __restrict__ w, int ld, int rows, int cols,
+                                                                unsigned char* __restrict__ w8, int ld8, float* __restrict__ rowscale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* wr = w + (size_t)row * ld;
+    float m = 0.f;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(bf2f(wr[c])));
+    m = wave_max(m);
+    const float scale = (m > 0.f) ? m / FP8_MAX : 1.0f;
+    const float inv = 1.0f / scale;
+    if (lane == 0) rowscale[row] = scale;
+    for (int c4 = lane; c4 < (ld8 >> 2); c4 += 64) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int c = c4 * 4 + e; v[e] = (c < cols) ? bf2f(wr[c]) * inv : 0.f; }
+        reinterpret_cast<unsigned int*>(w8 + (size_t)row * ld8)[c4] = pack_fp8x4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+hipError_t launch_quantize_weight_fp8(const bf16_t* w, int ld, int rows, int cols, unsigned char* w8, int ld8, float* rowscale,
+                                      hipStream_t s) {
+    if (ld8 % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivit_quantize_weight_fp8, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w, ld, rows, cols, w8, ld8, rowscale);
+    return hipGetLastError();
+}
+
+// out[n] = a * in[n]
+__global__ void ivit_scale_vec(const float* __restrict__ in, float a, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * in[i];
+}
+hipError_t launch_scale_vec(const float* in, float a, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(ivit_scale_vec, dim3(ceil_div(n, 256)), dim3(256), 0, s, in, a, out, n);
     return hipGetLastError();
 }
 

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "ivit_abi_version", "ivit_build_info", "ivit_last_error", "ivit_stage_count", "ivit_stage_shape",
     "ivit_unfold_offset", "ivit_create", "ivit_destroy", "ivit_set_weight", "ivit_weights_ready",
     "ivit_forward_host", "ivit_forward_device", "ivit_attention_map", "ivit_attention_map_host",
-    "ivit_debug_unfold", "ivit_profile_enable",
+    "ivit_fp8_calibrate", "ivit_fp8_scales", "ivit_debug_unfold", "ivit_profile_enable",
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
 )
 
@@ -32,7 +32,11 @@ class IvitConfigC(ctypes.Structure):
     _fields_ = [("image", ctypes.c_int32), ("patch", ctypes.c_int32), ("dim", ctypes.c_int32),
                 ("heads", ctypes.c_int32), ("layers", ctypes.c_int32), ("mlp", ctypes.c_int32),
                 ("classes", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("device", ctypes.c_int32),
-                ("max_batch", ctypes.c_int32)]
+                ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32)]
+
+
+ABI_VERSION = 2
+PRECISIONS = {"bf16": 0, "fp8": 1}
 
 
 _lib = None
@@ -72,6 +76,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_forward_device.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
         lib.ivit_attention_map.argtypes = [c_p, c_i, c_i, c_p, c_p, c_p]
         lib.ivit_attention_map_host.argtypes = [c_p, c_i, c_i, c_p, c_p, c_i64]
+        lib.ivit_fp8_calibrate.argtypes = [c_p, c_i, c_p, c_p]
+        lib.ivit_fp8_scales.argtypes = [c_p, ctypes.POINTER(ctypes.c_float), c_i]
         lib.ivit_debug_unfold.argtypes = [c_p, c_i, c_p, c_p, c_i, c_p]
         lib.ivit_profile_enable.argtypes = [c_p, c_i]
         lib.ivit_profile_reset.argtypes = [c_p]
@@ -88,9 +94,9 @@ class EngineError(Exception):
     """A non-zero return from libivit; str(e) is ivit_last_error() (-> HTTP 400 body, views.py:40-42)."""
 
 
-def _config_c(cfg: VitConfig, device: int = 0, max_batch: int = 1) -> IvitConfigC:
+def _config_c(cfg: VitConfig, device: int = 0, max_batch: int = 1, precision: str = "bf16") -> IvitConfigC:
     return IvitConfigC(cfg.image, cfg.patch, cfg.dim, cfg.heads, cfg.layers, cfg.mlp, cfg.classes,
-                       cfg.ln_eps, device, max_batch)
+                       cfg.ln_eps, device, max_batch, PRECISIONS[precision])
 
 
 def stage_names(cfg: VitConfig) -> List[str]:
@@ -117,14 +123,18 @@ def unfold_offset(image: int, patch: int, n: int, k: int) -> int:
 class Engine:
     """One ViT engine instance bound to one GPU (owns bf16 weights + workspaces on that device)."""
 
-    def __init__(self, cfg: VitConfig, state_dict: Dict[str, torch.Tensor], device: int = 0, max_batch: int = 1):
+    def __init__(self, cfg: VitConfig, state_dict: Dict[str, torch.Tensor], device: int = 0, max_batch: int = 1,
+                 precision: str = "bf16"):
         self.lib = load_library()
+        if self.lib.ivit_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libivit.so has ABI {self.lib.ivit_abi_version()}, this binding needs {ABI_VERSION}: rebuild")
         self.cfg = cfg
         self.device = int(device)
         self.max_batch = int(max_batch)
+        self.precision = precision
         self.stages = stage_names(cfg)
         self._h = ctypes.c_void_p()
-        c = _config_c(cfg, self.device, self.max_batch)
+        c = _config_c(cfg, self.device, self.max_batch, precision)
         self._check(self.lib.ivit_create(ctypes.byref(c), ctypes.byref(self._h)))
         try:
             for name, t in state_dict.items():
@@ -232,6 +242,22 @@ class Engine:
             return self.attention_map(int(suffix.split(".")[-2]), x)
         s = self.stage_index(suffix)
         return self.forward(x, s, s + 1)
+
+    # -- fp8 data path ------------------------------------------------------------------------
+    def calibrate_fp8(self, images: torch.Tensor) -> List[float]:
+        """One bf16 forward of `images` ([B,3,S,S] in [0,1]) to fix the static fp8 activation scales and
+        quantise the weights (include/ivit.h: ivit_fp8_calibrate).  Returns the L*4 scales."""
+        batch, _ = self._split_batch(images, 0)
+        xin = images.detach().to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        stream = torch.cuda.current_stream(xin.device).cuda_stream
+        self._check(self.lib.ivit_fp8_calibrate(self._h, batch, ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(stream)))
+        return self.fp8_scales()
+
+    def fp8_scales(self) -> List[float]:
+        n = 4 * self.cfg.layers
+        buf = (ctypes.c_float * n)()
+        self._check(self.lib.ivit_fp8_scales(self._h, buf, n))
+        return list(buf)
 
     def debug_unfold(self, x: torch.Tensor, normalise: bool) -> torch.Tensor:
         """bf16 unfold image the patch GEMM consumes, as f32 [B*Np, K] (parity-test inspection)."""

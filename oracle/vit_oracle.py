@@ -184,6 +184,93 @@ def encoder_layer(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> to
     return x + m @ _w(sd, pre + "mlp.3.weight", dt, emulate).t() + _w(sd, pre + "mlp.3.bias", dt)
 
 
+# ---- fp8 data path (BASELINE config 5): the engine's policy restated (include/ivit.h, ivit_fp8_calibrate)
+FP8_MAX = 448.0
+
+
+def q8_act(t: torch.Tensor, scale: float) -> torch.Tensor:
+    """Per-tensor static quantisation of an activation: sat_e4m3(t / scale) * scale."""
+    inv = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(scale, dtype=torch.float32))
+    q = (t * inv).clamp(-FP8_MAX, FP8_MAX).to(torch.float32).to(torch.float8_e4m3fn).to(t.dtype)
+    return q * scale
+
+
+def q8_weight(sd, key: str, dtype) -> torch.Tensor:
+    """Per-output-row quantisation of a weight matrix FROM ITS bf16 COPY (what the engine holds)."""
+    w = sd[key].to(torch.float32).to(torch.bfloat16).to(torch.float32)
+    amax = w.abs().amax(dim=1, keepdim=True)
+    scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax))
+    inv = 1.0 / scale                                   # f32, as on the device
+    q = (w * inv).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+    return (q * scale).to(dtype)
+
+
+def encoder_layer_fp8(x: torch.Tensor, sd, i: int, cfg, scales4) -> torch.Tensor:
+    """Block i on the fp8 data path: e4m3 operands for the four GEMMs (static activation scales
+    s_h1, s_att, s_h2, s_u; per-row weight scales), bf16 q|k|v and P, f32/f64 everything else."""
+    s_h1, s_att, s_h2, s_u = [float(v) for v in scales4]
+    dt = x.dtype
+    pre = layer_prefix(i)
+    b, n, d = x.shape
+    hd = cfg.head_dim
+    h = q8_act(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), s_h1)
+    qkv = rnd(h @ q8_weight(sd, pre + "self_attention.in_proj_weight", dt).t() + _w(sd, pre + "self_attention.in_proj_bias", dt), True)
+    q, k, v = [t.reshape(b, n, cfg.heads, hd).transpose(1, 2) for t in qkv.split(d, dim=-1)]
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+    a = (rnd(e, True) @ v) / e.sum(dim=-1, keepdim=True)
+    a = q8_act(a.transpose(1, 2).reshape(b, n, d), s_att)
+    x = x + a @ q8_weight(sd, pre + "self_attention.out_proj.weight", dt).t() + _w(sd, pre + "self_attention.out_proj.bias", dt)
+    h = q8_act(layer_norm(x, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps), s_h2)
+    u = q8_act(gelu_erf(h @ q8_weight(sd, pre + "mlp.0.weight", dt).t() + _w(sd, pre + "mlp.0.bias", dt)), s_u)
+    return x + u @ q8_weight(sd, pre + "mlp.3.weight", dt).t() + _w(sd, pre + "mlp.3.bias", dt)
+
+
+def fp8_calibration_scales(x: torch.Tensor, sd, cfg):
+    """The calibration the engine performs, on the oracle: one bf16-emulated forward, amax / 448 of
+    the four GEMM-input tensors of every layer (bf16-rounded, as the engine measures them)."""
+    t = x
+    for s_ in ("transform", "conv_proj", "tokens"):
+        t = run_node(s_, t, sd, cfg, emulate=True) if s_ != "transform" else transform(t.to(torch.float32)).to(x.dtype)
+    scales = []
+    for i in range(cfg.layers):
+        dt = t.dtype
+        pre = layer_prefix(i)
+        h1 = rnd(layer_norm(t, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), True)
+        att_in = attention(h1, sd, i, cfg, emulate=True)   # includes out-proj; recompute the pre-projection tensor below
+        # pre-projection attention output (bf16-rounded), as in attention(...)
+        b, n, d = h1.shape
+        qkv = rnd(h1 @ _w(sd, pre + "self_attention.in_proj_weight", dt, True).t() + _w(sd, pre + "self_attention.in_proj_bias", dt), True)
+        q, k, v = [z.reshape(b, n, cfg.heads, cfg.head_dim).transpose(1, 2) for z in qkv.split(d, dim=-1)]
+        sc = (q @ k.transpose(-1, -2)) / math.sqrt(cfg.head_dim)
+        e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+        a = rnd(((rnd(e, True) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(b, n, d), True)
+        t2 = t + att_in
+        h2 = rnd(layer_norm(t2, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps), True)
+        u = rnd(gelu_erf(h2 @ _w(sd, pre + "mlp.0.weight", dt, True).t() + _w(sd, pre + "mlp.0.bias", dt)), True)
+        t = t2 + u @ _w(sd, pre + "mlp.3.weight", dt, True).t() + _w(sd, pre + "mlp.3.bias", dt)
+        scales += [float(z.abs().max()) / FP8_MAX for z in (h1, a, h2, u)]
+    return scales
+
+
+def forward_fp8(x: torch.Tensor, sd, cfg, scales, keep: bool = False) -> Dict[str, torch.Tensor]:
+    """Whole model on the fp8 data path: patch embedding and head as in emulate=True (bf16), every
+    encoder layer through encoder_layer_fp8 with the given L*4 activation scales."""
+    acts: Dict[str, torch.Tensor] = {}
+    t = transform(x.to(torch.float32)).to(x.dtype)
+    t = tokens(conv_proj(t, sd, cfg, True), sd, cfg)
+    if keep:
+        acts["tokens"] = t
+    for i in range(cfg.layers):
+        t = encoder_layer_fp8(t, sd, i, cfg, scales[4 * i:4 * i + 4])
+        if keep:
+            acts[f"encoder.layers.{i}"] = t
+    t = encoder_ln(t, sd, cfg)
+    acts["cls"] = cls(t)
+    acts["logits"] = acts["heads"] = heads(acts["cls"], sd, True)
+    return acts
+
+
 def encoder_ln(x: torch.Tensor, sd, cfg) -> torch.Tensor:
     dt = x.dtype
     return layer_norm(x, _w(sd, "encoder.ln.weight", dt), _w(sd, "encoder.ln.bias", dt), cfg.ln_eps)

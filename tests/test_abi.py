@@ -35,14 +35,15 @@ def test_library_exports_every_declared_symbol(built_lib):
     exported = set(re.findall(r"\bT (ivit_[a-z_0-9]+)", out))
     assert set(header_symbols()) <= exported
     lib = engine.load_library()
-    assert lib.ivit_abi_version() == 1
+    assert lib.ivit_abi_version() == engine.ABI_VERSION == 2
     assert b"gfx950" in lib.ivit_build_info()
 
 
 def test_library_contains_gfx950_code_objects(built_lib):
     data = open(built_lib, "rb").read()
     assert b"gfx950" in data
-    for kernel in (b"ivit_gemm_bf16_128x128x64", b"ivit_attention_bf16", b"ivit_layernorm", b"ivit_unfold"):
+    for kernel in (b"ivit_gemm_bf16_128x128x64", b"ivit_gemm_bf16_160x128x64", b"ivit_gemm_bf16_256x256x64_stag",
+                   b"ivit_gemm_fp8_160x128x128", b"ivit_attention_bf16", b"ivit_layernorm", b"ivit_unfold"):
         assert kernel in data, kernel
 
 
@@ -86,7 +87,7 @@ def test_bad_configs_are_rejected_with_messages(built_lib):
     h = ctypes.c_void_p()
     for field, value, text in (("image", 230, "multiple of patch"), ("dim", 100, "multiple of 64"),
                                ("heads", 5, "divisible by heads"), ("max_batch", 0, "max_batch"),
-                               ("heads", 1, "head_dim")):
+                               ("heads", 1, "head_dim"), ("precision", 7, "precision")):
         cfg = small_config()
         c = engine._config_c(cfg, 0, 1)
         setattr(c, field, value)
