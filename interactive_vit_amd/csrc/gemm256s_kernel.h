@@ -33,7 +33,7 @@
 
 namespace ivit {
 
-template <int DBG>
+template <int DBG, bool FP8>
 __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt, f32x4 (&acc)[8][4],
                                             bf16x8 (&a)[4][2], bf16x8 (&b0)[2][2], bf16x8 (&b1)[2][2]) {
     const int s1 = min(t + 1, last_kt), s2 = min(t + 2, last_kt);   // clamped SOURCE K-tiles
@@ -44,7 +44,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
     IVIT_VMCNT(8);                       // B1(t) landed (read in SR2)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2) g256_mma<0, 0>(acc, a, b0);
+    if (DBG != 2) g256_mma<0, 0, FP8>(acc, a, b0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- SR2: stage A1(t+1) | read B1
@@ -53,7 +53,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
     IVIT_VMCNT(8);                       // A1(t) landed (read in SR3)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2) g256_mma<0, 1>(acc, a, b1);
+    if (DBG != 2) g256_mma<0, 1, FP8>(acc, a, b1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- SR3: stage A0(t+2) | read A1 (into the registers A0 just vacated)
@@ -61,7 +61,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
     g256_read_a(c, t, 1, a);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2) g256_mma<1, 1>(acc, a, b1);
+    if (DBG != 2) g256_mma<1, 1, FP8>(acc, a, b1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- SR4: stage B0(t+2) | nothing to read (B0 is still in registers)
@@ -69,7 +69,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
     IVIT_VMCNT(8);                       // A0(t+1), B0(t+1) landed (read in the next SR1)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2) g256_mma<1, 0>(acc, a, b0);
+    if (DBG != 2) g256_mma<1, 0, FP8>(acc, a, b0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
 }
@@ -87,7 +87,9 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
 #define IVIT_STAMP(slot) do { } while (0)
 #endif
 
-template <int DBG>
+// FP8: A and W are e4m3 BYTE matrices.  A K-tile is 128 bytes of every row either way, so the fp8
+// operands are staged as bf16 matrices of half the row length (lda, ldw % 16 == 0, K % 128 == 0).
+template <int DBG, bool FP8 = false>
 __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     using T = Tile256P;
     IVIT_STAMP(0);
@@ -102,12 +104,12 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     const int n0 = tn * T::BN;
 
     G256Ctx c;
-    c.smem = smem; c.wave = wave; c.lda = p.lda; c.ldw = p.ldw;
+    c.smem = smem; c.wave = wave; c.lda = FP8 ? p.lda / 2 : p.lda; c.ldw = FP8 ? p.ldw / 2 : p.ldw;
     {
         const int r_in = lane >> 3;
         const int chunk = (lane & 7) ^ r_in;
-        c.a_src = p.A + (size_t)(m0 + wave * 8 + r_in) * p.lda + chunk * 8;
-        c.w_src = p.W + (size_t)(n0 + (wave >> 2) * 64 + (wave & 3) * 8 + r_in) * p.ldw + chunk * 8;
+        c.a_src = p.A + (size_t)(m0 + wave * 8 + r_in) * c.lda + chunk * 8;
+        c.w_src = p.W + (size_t)(n0 + (wave >> 2) * 64 + (wave & 3) * 8 + r_in) * c.ldw + chunk * 8;
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -121,7 +123,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = p.K / GEMM_BK;
+    const int nt = p.K / (FP8 ? 2 * GEMM_BK : GEMM_BK);
     const int last_kt = nt - 1;
     // ---- prologue: DMA queue in steady-state order: tile 0 = A0 B0 B1 A1, tile 1 = A0 B0
     const int k1 = min(1, last_kt);
@@ -139,7 +141,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     if (late) __builtin_amdgcn_s_barrier();
 
     bf16x8 a[4][2], b0[2][2], b1[2][2];
-    for (int t = 0; t < nt; ++t) g256s_ktile<DBG>(c, t, last_kt, acc, a, b0, b1);
+    for (int t = 0; t < nt; ++t) g256s_ktile<DBG, FP8>(c, t, last_kt, acc, a, b0, b1);
 
     if (!late) __builtin_amdgcn_s_barrier();
     IVIT_STAMP(2);

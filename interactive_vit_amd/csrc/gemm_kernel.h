@@ -55,6 +55,19 @@ __device__ __forceinline__ void stage_tile(const void* __restrict__ g, size_t ld
     }
 }
 
+// v_mfma_scale_f32_16x16x128_f8f6f4 with e4m3 operands and unit block scales (e8m0 0x7f = 2^0): the
+// gfx950 fp8 form that runs at twice the bf16 rate (the non-scaled 16x16x32 fp8 MFMA runs at the bf16
+// rate).  w2 / a2 = the two 16-B k-chunks a lane holds of its W / A row; first source = W, so the
+// accumulator quad is C[m = lane & 15][n = (lane >> 4) * 4 + r] as for the bf16 form.  Semantics
+// checked on hardware by tools/mfma_f8_probe.hip.
+__device__ __forceinline__ f32x4 mfma_e4m3_16x16x128(const bf16x8 (&w2)[2], const bf16x8 (&a2)[2], f32x4 c) {
+    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+    const i32x8_t w = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, w2[0]), __builtin_bit_cast(i32x4_t, w2[1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8_t a = __builtin_shufflevector(__builtin_bit_cast(i32x4_t, a2[0]), __builtin_bit_cast(i32x4_t, a2[1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int r_local, int q) {
     const int off = r_local * 128 + ((q ^ (r_local & 7)) << 4);
     return *reinterpret_cast<const bf16x8*>(lds_tile + off);
@@ -261,34 +274,40 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
         }
         const char* a_tile = cur;
         const char* w_tile = cur + T::A_BYTES;
+        if (FP8) {
+            // one 128-deep MFMA per fragment pair and K-tile: a lane supplies the two 16-B k-chunks fq and
+            // 4 + fq of its row for both operands (the instruction's k order inside the 128-block is the
+            // same for both sources, so any consistent cut is a dot product over all 128 k)
+            bf16x8 af[T::FM][2], wf[T::FN][2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[T::FM], wf[T::FN];
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int j = 0; j < T::FN; ++j) wf[j] = read_frag(w_tile, (wc * T::FN + j) * 16 + fr, kk * 4 + fq);
+                for (int j = 0; j < T::FN; ++j) wf[j][kk] = read_frag(w_tile, (wc * T::FN + j) * 16 + fr, kk * 4 + fq);
 #pragma unroll
-            for (int i = 0; i < T::FM; ++i) af[i] = read_frag(a_tile, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+                for (int i = 0; i < T::FM; ++i) af[i][kk] = read_frag(a_tile, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+            }
             __builtin_amdgcn_s_setprio(1);
-            if (FP8) {
-                // a 16-B fragment holds 16 consecutive fp8 k: its two 8-B halves are the operands of two
-                // 32-deep MFMA steps (both operands are cut the same way, so the k pairing is consistent)
-                typedef __attribute__((ext_vector_type(2))) long l64x2;
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
+            for (int i = 0; i < T::FM; ++i)
 #pragma unroll
-                    for (int i = 0; i < T::FM; ++i)
+                for (int j = 0; j < T::FN; ++j) acc[i][j] = mfma_e4m3_16x16x128(wf[j], af[i], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
 #pragma unroll
-                        for (int j = 0; j < T::FN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(l64x2, wf[j])[hf],
-                                                                                   __builtin_bit_cast(l64x2, af[i])[hf], acc[i][j], 0, 0, 0);
-            } else {
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[T::FM], wf[T::FN];
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) wf[j] = read_frag(w_tile, (wc * T::FN + j) * 16 + fr, kk * 4 + fq);
+#pragma unroll
+                for (int i = 0; i < T::FM; ++i) af[i] = read_frag(a_tile, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < T::FM; ++i)
 #pragma unroll
                     for (int j = 0; j < T::FN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
             }
-            __builtin_amdgcn_s_setprio(0);
         }
     }
     gemm_epilogue<T>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq);

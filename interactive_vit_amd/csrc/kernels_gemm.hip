@@ -1,5 +1,6 @@
 // Instantiations of the bf16 MFMA GEMM template (gemm_kernel.h) and the per-shape tile choice.
 #include "gemm256ps_kernel.h"
+#include "gemm160x256_kernel.h"
 #include <cmath>
 
 namespace ivit {
@@ -30,7 +31,15 @@ __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x6
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm256s_body<0>(p, smem);
 }
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_fp8_256x256x128_stag(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256s_body<0, true>(p, smem);
+}
 #ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost, and timing ablations
+__global__ __launch_bounds__(Tile160x256::THREADS, 2) void ivit_gemm_bf16_160x256x64(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm160x256_body(p, smem);
+}
 __global__ __launch_bounds__(Tile256::THREADS, 2) void ivit_gemm_bf16_256x256x64(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_body<Tile256>(p, smem);
@@ -68,6 +77,7 @@ const char* gemm_variant_name(int v) {
         case GEMM_TILE_256: return "ivit_gemm_bf16_256x256x64";
         case GEMM_TILE_256P: return "ivit_gemm_bf16_256x256x64_pipe";
         case GEMM_TILE_256S: return "ivit_gemm_bf16_256x256x64_stag";
+        case GEMM_TILE_160X256: return "ivit_gemm_bf16_160x256x64";
         case GEMM_TILE_256PS: return "ivit_gemm_bf16_256x256x64_persist";
     }
     return "?";
@@ -97,8 +107,18 @@ static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream)
 // workgroup per CU, so its epilogue (13 us for an f32 residual tile, in-kernel stamps) is not hidden
 // by another workgroup's main loop and its grid quantises worse.  It wins only on wide, bf16-output
 // shapes with >= 2 rounds of tiles.
+// On the ViT-L / ViT-H shapes (M = 73856 / 65792 token rows, 4.5+ rounds of 256 x 256 tiles) the
+// staggered 256 x 256 kernel wins every shape by 10-20 % (qkv 1125-1167 vs 929-972 TFLOP/s, mlp2
+// 1122-1131 vs 905-953; hipBLASLt: 1210-1260), so the rule is "enough rounds to amortise the
+// exposed epilogue and the ragged last round".
+static bool gemm_prefers_256(int M, int N, int K) {
+    if (N >= 2048 && N <= 2560 && K <= 1024 && M >= 4096) return true;   // ViT-B QKV-like (1.8 rounds, bf16 out)
+    const double rounds = (double)ceil_div(M, 256) * ceil_div(N, 256) / 256.0;
+    return rounds >= 3.0;
+}
+
 int gemm_pick_variant(int M, int N, int K) {
-    if (N >= 2048 && N <= 2560 && K <= 1024 && M >= 4096) return GEMM_TILE_256S;   // QKV-like
+    if (gemm_prefers_256(M, N, K)) return GEMM_TILE_256S;
     struct Cand { int v, bm, bn; double speed; };
     static const Cand cands[] = {
         {GEMM_TILE_160, Tile160::BM, Tile160::BN, 1.03},
@@ -159,6 +179,7 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
         case GEMM_TILE_256PS:
             if (p.K < 2 * GEMM_BK) return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag, p, stream);
             return launch_persistent(p, stream);
+        case GEMM_TILE_160X256: return launch_tile<Tile160x256>(ivit_gemm_bf16_160x256x64, p, stream);
 #endif
         case GEMM_TILE_256S:
 #ifdef IVIT_GEMM_ABLATIONS
@@ -177,6 +198,7 @@ hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
     struct Cand { int bm, bn; double speed; };
     const double t160 = std::ceil((double)ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) / 512.0) * Tile160::BM / 1.03;
     const double t128 = std::ceil((double)ceil_div(p.M, Tile128::BM) * ceil_div(p.N, Tile128::BN) / 512.0) * Tile128::BM;
+    if (gemm_prefers_256(p.M, p.N, p.K)) return launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag, p, stream);
     if (t160 <= t128) return launch_tile<Tile160>(ivit_gemm_fp8_160x128x128, p, stream);
     return launch_tile<Tile128>(ivit_gemm_fp8_128x128x128, p, stream);
 }

@@ -36,7 +36,16 @@ int main(int argc, char** argv) {
         {"mlp1  ", Mfull, 3072, 768, EPI_BIAS_GELU_BF16}, {"mlp2  ", Mfull, 768, 3072, EPI_BIAS_RESID_F32},
         {"patch ", 64 * 196, 768, 768, EPI_BIAS_F32}, {"mlp1ng", Mfull, 3072, 768, EPI_BIAS_BF16},
     };
-    const int maxM = round_up(Mfull, 256) + 256, maxN = 3072, maxK = 3072;
+    const char* set = getenv("IVIT_SHAPES");   // "vith": the ViT-H/14 layer shapes (dim 1280, mlp 5120)
+    if (set && !strcmp(set, "vith"))
+        shapes = {{"h_qkv ", Mfull, 3840, 1280, EPI_BIAS_BF16}, {"h_proj", Mfull, 1280, 1280, EPI_BIAS_RESID_F32},
+                  {"h_mlp1", Mfull, 5120, 1280, EPI_BIAS_GELU_BF16}, {"h_mlp2", Mfull, 1280, 5120, EPI_BIAS_RESID_F32}};
+    if (set && !strcmp(set, "vitl"))
+        shapes = {{"l_qkv ", Mfull, 3072, 1024, EPI_BIAS_BF16}, {"l_proj", Mfull, 1024, 1024, EPI_BIAS_RESID_F32},
+                  {"l_mlp1", Mfull, 4096, 1024, EPI_BIAS_GELU_BF16}, {"l_mlp2", Mfull, 1024, 4096, EPI_BIAS_RESID_F32}};
+    int maxN = 0, maxK = 0;
+    for (const Shape& s : shapes) { maxN = std::max(maxN, s.N); maxK = std::max(maxK, s.K); }
+    const int maxM = round_up(Mfull, 256) + 256;
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> u(-1.f, 1.f);
     std::vector<bf16_t> hA((size_t)maxM * maxK), hW((size_t)maxN * maxK);
