@@ -195,7 +195,12 @@ def main():
         traffic = None
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]
-            ks = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
+            pj = json.load(open(os.path.join(ROOT, "profiles", prof)))
+            ks = pj["kernels"]
+            # the counters belong to one workload (summaries without a "workload" key: the default one)
+            if pj.get("workload", "--model vit_b_16 --batch-per-gpu 64 --precision bf16") != \
+                    f"--model {args.model} --batch-per-gpu {B} --precision {args.precision}":
+                ks = {}
             tot = n = 0.0
             for name, rec in ks.items():
                 if "gemm" in name and rec.get("hbm_bytes_per_launch"):
@@ -205,10 +210,11 @@ def main():
                 traffic = {"hbm_bytes_per_launch": round(tot / n), "source": f"profiles/{prof}"}
         except Exception:
             traffic = None
-        roofline = {"bound": "mfma", "kernel": "ivit_gemm_fp8_160x128x128" if args.precision == "fp8" else
-                    "ivit_gemm_bf16_160x128x64 (+ ivit_gemm_bf16_256x256x64_stag for QKV)",
+        roofline = {"bound": "mfma",
+                    "kernel": ("ivit_gemm_fp8_{160x128,256x256_stag}x128" if args.precision == "fp8" else
+                               "ivit_gemm_bf16_{160x128,256x256_stag}x64") + " (all GEMM launches of the step; tile picked per shape)",
                     "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic if args.precision == "bf16" else None,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_per_step": g["launches"] // args.steps, "avg_launch_us": round(avg_us, 2),
                     "algorithmic_gflop_per_step": round(g["flops"] / args.steps / 1e9, 2),
                     "measured": "HIP events on the launch stream around every launch, separate instrumented pass of the same K steps",

@@ -2,9 +2,10 @@
 //
 //     out[b, q, h*64 + d] = sum_key softmax_key(scale * Q[q].K[key]) * V[key][d]
 //
-// One workgroup = one (image, head) [or a 256-query slice of it for long sequences]; K and V of the
-// head are staged ONCE into LDS with plain 16-byte copies (197 keys: 28 KiB + 28 KiB, two workgroups
-// per CU).  Each wave owns QB x 16 queries.  All keys fit on chip, so the softmax is a single exact
+// One workgroup = one (image, head) at every supported length; K and V of the head are staged ONCE
+// into LDS by LDS-DMA (global_load_lds_dwordx4: every chunk of the head in flight at once, no
+// VGPRs, no ds_write; 197 keys: 28 KiB + 28 KiB, two workgroups per CU).  The 16-query blocks of the
+// head are dealt round-robin to the (up to 8) waves.  All keys fit on chip, so the softmax is a single exact
 // pass with every score of the wave's queries held in registers - no online rescaling at these
 // lengths.  Both contractions run on v_mfma_f32_16x16x32_bf16 with the key index on the
 // accumulator ROW:
@@ -26,7 +27,7 @@ namespace ivit {
 // Head dims: 64 (ViT-Ti/B/L: 128-B LDS rows, XOR-swizzled chunks) and 80 (ViT-H/14: 160 B of data in
 // 176-B rows - an odd number of 16-B chunks spreads rows over the banks without a swizzle; the
 // third 32-deep MFMA step of Q.K^T covers d = 64..95 with 80..95 supplied as zero fragments).
-template <int DH, int NKF, int QB>
+template <int DH, int NKF>
 struct AttLayout {
     static_assert(DH == 64 || DH == 80, "head dim 64 or 80");
     static constexpr int KEYS = NKF * 16;
@@ -37,7 +38,9 @@ struct AttLayout {
     static constexpr int K_BYTES = KEYS * ROW;
     static constexpr int V_BYTES = KEYS * ROW;
     static constexpr int LDS_BYTES = K_BYTES + V_BYTES;
-    static constexpr int QPW = QB * 16;   // queries per wave
+    static constexpr int CPR = ROW / 16;                      // 16-B chunk slots per LDS row (dh 80: 10 data + 1 pad)
+    static constexpr int K_SWZ = 0, V_SWZ = 1;
+    __device__ static int swz(int which, int key) { return DH == 64 ? (which == K_SWZ ? (key & 7) : (((key >> 1) & 3) << 1)) : 0; }
     __device__ static int k_off(int key, int ch) { return key * ROW + ((DH == 64 ? (ch ^ (key & 7)) : ch) << 4); }
     __device__ static int v_off(int key, int ch) { return key * ROW + ((DH == 64 ? (ch ^ (((key >> 1) & 3) << 1)) : ch) << 4); }
 };
@@ -50,9 +53,32 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
 
 // PROBS = true: the inspection variant behind the `encoder.layers.<i>.attn` node - same staging, QK^T and
 // softmax, but instead of P.V it writes the normalised probabilities as f32 [B, H, N, N].
-template <int DH, int NKF, int QB, bool PROBS>
+// Stages one operand (K or V columns of the head) into its LDS image.  The image is addressed as a
+// linear array of 16-B chunk slots; one DMA instruction fills 64 consecutive slots (LDS address =
+// wave-uniform base + 16 * lane) from per-lane source addresses, which is where the row swizzle goes.
+// Slots of keys >= N get zeros by ds_write from the lane that would have loaded them (0 * garbage must
+// not be NaN in P.V); pad slots (dh 80) are never read and stay untouched.
+template <class L>
+__device__ __forceinline__ void att_stage(char* lds, const bf16_t* src0, int ld, int N, int which, int wave, int nwaves, int lane) {
+    constexpr int SLOTS = L::KEYS * L::CPR;
+    constexpr int INSTR = (SLOTS + 63) / 64;
+    for (int i = wave; i < INSTR; i += nwaves) {
+        const int slot = i * 64 + lane;
+        const int key = slot / L::CPR, cl = slot % L::CPR;
+        const bool data = slot < SLOTS && cl < L::CHUNKS;
+        if (data && key < N) {
+            const int ch = cl ^ L::swz(which, key);   // the data chunk that lives in slot cl of this row
+            __builtin_amdgcn_global_load_lds((const IVIT_GLOBAL void*)(src0 + (size_t)key * ld + ch * 8),
+                                             (IVIT_LDS void*)(lds + i * 1024), 16, 0, 0);
+        } else if (data) {
+            *reinterpret_cast<u32x4*>(lds + slot * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+
+template <int DH, int NKF, bool PROBS>
 __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
-    using L = AttLayout<DH, NKF, QB>;
+    using L = AttLayout<DH, NKF>;
     constexpr int ATT_DH = DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
@@ -68,10 +94,16 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     const bf16_t* qkv = p.qkv;
     const int ld = p.ldqkv;
 
-    const int q0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * L::QPW;
+    const int nwaves = blockDim.x >> 6;
+    const int nblocks = (N + 15) >> 4;   // 16-query blocks; the launcher gives every wave at least one
+    const int q0 = wave * 16;
 
-    // ---- Q fragments of the wave's first query block: issued BEFORE the staging barrier so that their
-    // latency overlaps the K/V staging (B operand: lane holds Q[q + fr][kk*32 + 8g .. +7])
+    // ---- K and V by LDS-DMA (row-major, 16-B chunks, swizzle applied on the source address)
+    att_stage<L>(k_lds, qkv + row0 * ld + h * ATT_DH + D, ld, N, L::K_SWZ, wave, nwaves, lane);
+    att_stage<L>(v_lds, qkv + row0 * ld + h * ATT_DH + 2 * D, ld, N, L::V_SWZ, wave, nwaves, lane);
+
+    // ---- Q fragments of the wave's first query block, behind the DMA queue so that their latency
+    // overlaps the staging (B operand: lane holds Q[q + fr][kk*32 + 8g .. +7])
     const bf16x8 zero_frag = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 qf[L::KSTEPS];
     {
@@ -81,50 +113,21 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
             qf[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
                          ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8) : zero_frag;
     }
-
-    // ---- stage K and V (row-major, 16-B chunks; rows >= N are zero: 0 * garbage must not be NaN).
-    // Batches of 4 chunks per thread: all 8 global loads of a batch are in flight before the first
-    // LDS store (a plain loop serialised load -> wait -> store per chunk).
-    for (int c0 = threadIdx.x; c0 < L::KEYS * L::CHUNKS; c0 += 4 * blockDim.x) {
-        u32x4 kv[4], vv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = c0 + i * blockDim.x;
-            const int key = c / L::CHUNKS, ch = c % L::CHUNKS;
-            kv[i] = u32x4{0u, 0u, 0u, 0u};
-            vv[i] = u32x4{0u, 0u, 0u, 0u};
-            if (c < L::KEYS * L::CHUNKS && key < N) {
-                const bf16_t* src = qkv + (row0 + key) * ld + h * ATT_DH + ch * 8;
-                kv[i] = *reinterpret_cast<const u32x4*>(src + D);
-                vv[i] = *reinterpret_cast<const u32x4*>(src + 2 * D);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = c0 + i * blockDim.x;
-            const int key = c / L::CHUNKS, ch = c % L::CHUNKS;
-            if (c < L::KEYS * L::CHUNKS) {
-                *reinterpret_cast<u32x4*>(k_lds + L::k_off(key, ch)) = kv[i];
-                *reinterpret_cast<u32x4*>(v_lds + L::v_off(key, ch)) = vv[i];
-            }
-        }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed; the barrier publishes everyone's
     __syncthreads();
-
-    if (q0 >= N) return;  // whole wave idle (after the only barrier)
 
     // transposed-read addressing: lane i = 4q + p of its 16-lane group supplies &V[key0 + q][d0 + 4p]
     const int tq = fr >> 2, tp = fr & 3;
     const float cexp = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*scale*log2 e)
 
-    // The wave's QB 16-query blocks run one after the other, so only one block's scores (NKF x 4
-    // registers) are live at a time: < 128 VGPRs at 197 keys, i.e. two 7-wave workgroups per CU and
-    // one's staging overlaps the other's math.  (K / V fragments are re-read per block: LDS has room.)
+    // The wave's 16-query blocks (wave, wave + nwaves, ...) run one after the other, so only one block's
+    // scores (NKF x 4 registers) are live at a time: < 128 VGPRs at 197 keys, i.e. two workgroups per
+    // CU and one's staging overlaps the other's math.  (K / V fragments are re-read per block: LDS has room.)
 #pragma unroll 1
-    for (int c = 0; c < QB; ++c) {
-        const int qbase = q0 + c * 16;
-        if (qbase >= N) break;   // wave-uniform
-        if (c > 0) {   // later blocks: plain load (the first block's fragments were prefetched above)
+    for (int blk = wave; blk < nblocks; blk += nwaves) {
+        const int qbase = blk * 16;
+        asm volatile("" ::: "memory");   // keeps the (block-invariant) K / V fragment reads inside the loop: hoisted, they cost 100+ VGPRs
+        if (blk != wave) {   // later blocks: plain load (the first block's fragments were prefetched above)
             const int qrow = min(qbase + fr, N - 1);
 #pragma unroll
             for (int kk = 0; kk < L::KSTEPS; ++kk)
@@ -243,26 +246,26 @@ bool attention_supported(int tokens, int head_dim) {
     return false;
 }
 
-template <int DH, int NKF, int QB, bool PROBS>
+template <int DH, int NKF, bool PROBS>
 static hipError_t launch_nkf_impl(const AttnParams& p, hipStream_t stream) {
-    using L = AttLayout<DH, NKF, QB>;
+    using L = AttLayout<DH, NKF>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<DH, NKF, QB, PROBS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<DH, NKF, PROBS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int waves_needed = ceil_div(p.tokens, L::QPW);
-    const int wpb = waves_needed < 8 ? waves_needed : 8;          // waves per workgroup
-    dim3 grid(ceil_div(waves_needed, wpb), p.heads, p.batch);
-    hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, QB, PROBS>), grid, dim3(wpb * 64), L::LDS_BYTES, stream, p);
+    const int blocks = ceil_div(p.tokens, 16);
+    const int waves = blocks < 8 ? blocks : 8;                    // every wave gets at least one 16-query block
+    dim3 grid(1, p.heads, p.batch);
+    hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, PROBS>), grid, dim3(waves * 64), L::LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 
-template <int DH, int NKF, int QB>
+template <int DH, int NKF>
 static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
-    return p.probs ? launch_nkf_impl<DH, NKF, QB, true>(p, stream) : launch_nkf_impl<DH, NKF, QB, false>(p, stream);
+    return p.probs ? launch_nkf_impl<DH, NKF, true>(p, stream) : launch_nkf_impl<DH, NKF, false>(p, stream);
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
@@ -270,18 +273,18 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if ((p.ldqkv % 8) || (!p.probs && !p.out8 && (p.ldo % 4)) || (p.out8 && (p.ldo8 % 4))) return hipErrorInvalidValue;
     const int nkf = round_up(ceil_div(p.tokens, 16), 2);
     if (p.head_dim == 80) {
-        if (nkf <= 2) return launch_nkf<80, 2, 2>(p, stream);
-        if (nkf <= 8) return launch_nkf<80, 8, 2>(p, stream);
-        if (nkf <= 18) return launch_nkf<80, 18, 2>(p, stream);   // ViT-H/14: 257 tokens
-        return launch_nkf<80, 26, 1>(p, stream);
+        if (nkf <= 2) return launch_nkf<80, 2>(p, stream);
+        if (nkf <= 8) return launch_nkf<80, 8>(p, stream);
+        if (nkf <= 18) return launch_nkf<80, 18>(p, stream);   // ViT-H/14: 257 tokens
+        return launch_nkf<80, 26>(p, stream);
     }
-    if (nkf <= 2) return launch_nkf<64, 2, 2>(p, stream);
-    if (nkf <= 4) return launch_nkf<64, 4, 2>(p, stream);
-    if (nkf <= 8) return launch_nkf<64, 8, 2>(p, stream);
-    if (nkf <= 14) return launch_nkf<64, 14, 2>(p, stream);   // 197 tokens (224^2 / 16): 7 waves x 32 queries
-    if (nkf <= 18) return launch_nkf<64, 18, 2>(p, stream);   // 257 tokens (224^2 / 14)
-    if (nkf <= 26) return launch_nkf<64, 26, 1>(p, stream);
-    return launch_nkf<64, 38, 1>(p, stream);                  // 577 tokens (384^2 / 16): 16 queries per wave
+    if (nkf <= 2) return launch_nkf<64, 2>(p, stream);
+    if (nkf <= 4) return launch_nkf<64, 4>(p, stream);
+    if (nkf <= 8) return launch_nkf<64, 8>(p, stream);
+    if (nkf <= 14) return launch_nkf<64, 14>(p, stream);   // 197 tokens (224^2 / 16)
+    if (nkf <= 18) return launch_nkf<64, 18>(p, stream);   // 257 tokens (224^2 / 14)
+    if (nkf <= 26) return launch_nkf<64, 26>(p, stream);
+    return launch_nkf<64, 38>(p, stream);                  // 577 tokens (384^2 / 16)
 }
 
 }  // namespace ivit

@@ -16,9 +16,13 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.log 2>&1
 cp $OUT/stats/*/*_kernel_stats.csv profiles/${TAG}_kernel_stats.csv
 tail -1 $OUT/stats.log > profiles/${TAG}_bench_under_rocprof.json || true
-python3 - "$OUT" "$TAG" <<'PY'
-import csv, glob, json, sys, collections
-out, tag = sys.argv[1], sys.argv[2]
+python3 - "$OUT" "$TAG" "$*" <<'PY'
+import csv, glob, json, sys, collections, re
+out, tag, extra = sys.argv[1], sys.argv[2], sys.argv[3]
+def opt(name, default):
+    m = re.search(name + r"[ =](\S+)", extra)
+    return m.group(1) if m else default
+workload = f"--model {opt('--model', 'vit_b_16')} --batch-per-gpu {opt('--batch-per-gpu', '64')} --precision {opt('--precision', 'bf16')}"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -38,7 +42,7 @@ for k, d in sorted(agg.items()):
     if r["hbm_read_bytes_per_launch"] is not None and r["hbm_write_bytes_per_launch"] is not None:
         r["hbm_bytes_per_launch"] = r["hbm_read_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 10; FETCH_SIZE x2 (gfx950 correction)",
-           "kernels": res}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+           "workload": workload, "kernels": res}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 for k, r in res.items():
     print(f"{k:50s} read {r['hbm_read_bytes_per_launch']}  write {r['hbm_write_bytes_per_launch']}")
 PY
