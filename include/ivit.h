@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define IVIT_ABI_VERSION 2
+#define IVIT_ABI_VERSION 3
 
 #define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
 #define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
@@ -92,6 +92,18 @@ int ivit_weights_ready(ivit_engine* e);
  * out_capacity is in floats; fails if the result does not fit. */
 int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end, int batch,
                       const float* in, float* out, int64_t out_capacity);
+
+/* Chained form of ivit_forward_host for a request that walks a chain of nodes (Context.compute calls
+ * one node after the other and hands node k's output tensor to node k+1 by reference,
+ * main/context.py:143-147, main/graph.py:22-29).  The f32 output of every host
+ * call also stays on the device; *out_token names it.  A call that passes that token as in_token -
+ * the caller asserting that `in` still holds exactly the bytes it was given back then - skips the
+ * upload and consumes the resident copy (bit-identical: both are the same f32 values).  A stale,
+ * foreign or zero token falls back to uploading `in`, which must therefore always be valid.
+ * Any later host call invalidates older tokens. */
+int ivit_forward_host_chained(ivit_engine* e, int stage_begin, int stage_end, int batch,
+                              const float* in, float* out, int64_t out_capacity,
+                              uint64_t in_token, uint64_t* out_token);
 
 /* Device-pointer form (benchmark / chained nodes): `in` and `out` are device f32 buffers on the
  * engine's device, work is enqueued on `stream` (a hipStream_t; NULL = the null stream) and the

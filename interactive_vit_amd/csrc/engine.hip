@@ -157,7 +157,12 @@ struct ivit_engine {
     // sequence of a (stage range, batch) is captured once and replayed.  IVIT_GRAPHS=0 disables.
     bool graphs_on = true;
     int graph_max_batch = 4;
-    std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
+    std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;   // (begin, end, batch, which buffer is the input)
+    // chained host calls: the f32 output of the last host call stays in ext_out; a call that presents that
+    // call's token takes it as its input (the two ext buffers swap roles) instead of uploading it again
+    float* ext_buf0 = nullptr;
+    uint64_t resident_token = 0, token_counter = 0;
+    int64_t resident_elems = 0;
 
     // profiling
     bool prof_on = false;
@@ -294,6 +299,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     e->ext_elems = per_img * B;
     chk(alloc_vec(e, &e->ext_in, e->ext_elems));
     chk(alloc_vec(e, &e->ext_out, e->ext_elems));
+    e->ext_buf0 = e->ext_in;
     e->upload_elems = std::max<int64_t>((int64_t)3 * D * D, std::max<int64_t>((int64_t)Mlp * D, std::max<int64_t>((int64_t)e->N * D, (int64_t)cfg->classes * D)));
     e->upload_elems = std::max<int64_t>(e->upload_elems, (int64_t)D * e->K);
     chk(alloc_vec(e, &e->upload, e->upload_elems));
@@ -667,8 +673,8 @@ extern "C" int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_en
     return rc;
 }
 
-extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end, int batch, const float* in, float* out,
-                                 int64_t out_capacity) {
+static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int batch, const float* in, float* out,
+                             int64_t out_capacity, uint64_t in_token, uint64_t* out_token) {
     if (check_range(e, stage_begin, stage_end, batch)) return 1;
     if (!in || !out) return fail("ivit_forward_host: null buffer");
     const int64_t n_in = shape_elems(&e->cfg, stage_begin, 0) * batch;
@@ -678,11 +684,19 @@ extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end,
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = e->own_stream;
     if (ws_acquire(e, st)) return 1;
-    HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
-    const bool use_graph = e->graphs_on && !e->prof_on && batch <= e->graph_max_batch && (stage_end - stage_begin) > 1;
+    if (in_token != 0 && in_token == e->resident_token && n_in == e->resident_elems) {
+        std::swap(e->ext_in, e->ext_out);   // the previous call's output is this call's input: no upload
+    } else {
+        HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
+    }
+    e->resident_token = 0;                  // ext_out is about to be overwritten
+    const int L = e->cfg.layers;
+    const bool many_launches = (stage_end - stage_begin) > 1 || (stage_begin >= ST_LAYER0 && stage_begin < ST_LAYER0 + L);
+    const bool use_graph = e->graphs_on && !e->prof_on && batch <= e->graph_max_batch && many_launches;
+    bool done = false;
     if (use_graph) {
         if (require_weights(e)) return 1;
-        const auto key = std::make_tuple(stage_begin, stage_end, batch);
+        const auto key = std::make_tuple(stage_begin, stage_end, batch, e->ext_in == e->ext_buf0 ? 0 : 1);
         auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
             // first request of this shape: run it eagerly (this also performs every one-time
@@ -692,6 +706,8 @@ extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end,
             HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamSynchronize(st));
+            // the capture replays the launches on the same buffers; an encoder layer updates its input
+            // in place only after copying it to the workspace, so ext_in is still intact
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             const int rc = forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st);
             const hipError_t ce = hipStreamEndCapture(st, &graph);
@@ -702,16 +718,30 @@ extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end,
             (void)hipGraphDestroy(graph);
             if (ie != hipSuccess) return fail("hipGraphInstantiate failed: %s", hipGetErrorString(ie));
             e->graphs.emplace(key, exec);
-            return ws_release(e, st);   // the eager run above already produced this request's output
+            done = true;   // the eager run above already produced this request's output
+        } else {
+            HIP_TRY(hipGraphLaunch(it->second, st));
         }
-        HIP_TRY(hipGraphLaunch(it->second, st));
     } else {
         if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
     }
-    HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    if (!done) HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
     if (ws_release(e, st)) return 1;
-    HIP_TRY(hipStreamSynchronize(st));
+    if (!done) HIP_TRY(hipStreamSynchronize(st));
+    e->resident_token = ++e->token_counter;
+    e->resident_elems = n_out;
+    if (out_token) *out_token = e->resident_token;
     return 0;
+}
+
+extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end, int batch, const float* in, float* out,
+                                 int64_t out_capacity) {
+    return forward_host_impl(e, stage_begin, stage_end, batch, in, out, out_capacity, 0, nullptr);
+}
+
+extern "C" int ivit_forward_host_chained(ivit_engine* e, int stage_begin, int stage_end, int batch, const float* in, float* out,
+                                         int64_t out_capacity, uint64_t in_token, uint64_t* out_token) {
+    return forward_host_impl(e, stage_begin, stage_end, batch, in, out, out_capacity, in_token, out_token);
 }
 
 // caller holds e->mu and has set the device

@@ -7,6 +7,7 @@ tensors cross the ABI as raw ``data_ptr()`` addresses.
 from __future__ import annotations
 
 import ctypes
+import weakref
 import os
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -22,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libivit.so")
 ABI_SYMBOLS = (
     "ivit_abi_version", "ivit_build_info", "ivit_last_error", "ivit_stage_count", "ivit_stage_shape",
     "ivit_unfold_offset", "ivit_create", "ivit_destroy", "ivit_set_weight", "ivit_weights_ready",
-    "ivit_forward_host", "ivit_forward_device", "ivit_attention_map", "ivit_attention_map_host",
+    "ivit_forward_host", "ivit_forward_host_chained", "ivit_forward_device", "ivit_attention_map", "ivit_attention_map_host",
     "ivit_fp8_calibrate", "ivit_fp8_scales", "ivit_debug_unfold", "ivit_profile_enable",
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
 )
@@ -35,7 +36,7 @@ class IvitConfigC(ctypes.Structure):
                 ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PRECISIONS = {"bf16": 0, "fp8": 1}
 
 
@@ -73,6 +74,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_set_weight.argtypes = [c_p, ctypes.c_char_p, c_p, ctypes.POINTER(c_i64), c_i]
         lib.ivit_weights_ready.argtypes = [c_p]
         lib.ivit_forward_host.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64]
+        lib.ivit_forward_host_chained.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         lib.ivit_forward_device.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
         lib.ivit_attention_map.argtypes = [c_p, c_i, c_i, c_p, c_p, c_p]
         lib.ivit_attention_map_host.argtypes = [c_p, c_i, c_i, c_p, c_p, c_i64]
@@ -129,6 +131,8 @@ class Engine:
         if self.lib.ivit_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libivit.so has ABI {self.lib.ivit_abi_version()}, this binding needs {ABI_VERSION}: rebuild")
         self.cfg = cfg
+        self._pin = os.environ.get("IVIT_PINNED_OUTPUTS", "1") != "0"
+        self._last_out = None     # (weakref to the last host-path output, its version counter, its residency token)
         self.device = int(device)
         self.max_batch = int(max_batch)
         self.precision = precision
@@ -192,10 +196,21 @@ class Engine:
         oshape = self.out_shape(end - 1)
         full = ((batch,) + oshape) if batched else oshape
         if x.device.type == "cpu":
+            # node chains: when `x` is the very tensor the previous host call returned (Context.compute
+            # hands outputs on by reference) and nobody wrote to it since, its device-resident copy is
+            # consumed instead of uploading it again (include/ivit.h: ivit_forward_host_chained)
+            token = 0
+            last = self._last_out
+            if last is not None and last[0]() is x and x._version == last[1]:
+                token = last[2]
             xin = x.detach().to(torch.float32).contiguous()
-            out = torch.empty(full, dtype=torch.float32)
-            self._check(self.lib.ivit_forward_host(self._h, begin, end, batch, ctypes.c_void_p(xin.data_ptr()),
-                                                   ctypes.c_void_p(out.data_ptr()), out.numel()))
+            # page-locked result buffer (torch caches the blocks): the D2H copy runs at DMA speed
+            out = torch.empty(full, dtype=torch.float32, pin_memory=self._pin)
+            new_token = ctypes.c_uint64(0)
+            self._check(self.lib.ivit_forward_host_chained(self._h, begin, end, batch, ctypes.c_void_p(xin.data_ptr()),
+                                                           ctypes.c_void_p(out.data_ptr()), out.numel(),
+                                                           ctypes.c_uint64(token), ctypes.byref(new_token)))
+            self._last_out = (weakref.ref(out), out._version, new_token.value)
             return out
         if x.device.type != "cuda" or (x.device.index or 0) != self.device:
             raise EngineError(f"input lives on {x.device}, engine on cuda:{self.device}")

@@ -316,6 +316,48 @@ def test_host_path_graph_replay_is_bit_identical(small):
         assert torch.equal(other, dev)
 
 
+def test_chained_host_calls_consume_the_resident_copy(small):
+    """Context.compute hands node k's output tensor to node k+1 by reference; the
+    engine then continues from the device-resident copy instead of uploading it again
+    (ivit_forward_host_chained).  The result must be bit-identical to independent calls, and every way
+    the residency can be stale must fall back to the bytes of the tensor actually passed."""
+    cfg, sd, eng = small
+    ns = len(eng.stages)
+    img = synthetic_images(1, cfg, seed=21)[0]
+    # independent calls: every stage gets a fresh copy of its input (no identity -> plain upload)
+    indep, x = [], img
+    for s in range(ns):
+        x = eng.forward(x.clone(), s, s + 1)
+        indep.append(x)
+    for rep in range(3):                      # rep 0 eager + capture, later reps replay the graphs
+        x = img
+        for s in range(ns):
+            x = eng.forward(x, s, s + 1)      # same object handed on: chained
+            assert torch.equal(x, indep[s]), f"stage {s} differs when chained (rep {rep})"
+    # stale residency 1: another request ran in between
+    a = eng.forward(img, 0, 1)
+    eng.forward(synthetic_images(1, cfg, seed=22)[0], 0, 2)
+    assert torch.equal(eng.forward(a, 1, 2), indep[1])
+    # stale residency 2: the tensor was modified in place after it was returned
+    a = eng.forward(img, 0, 1)
+    a.mul_(0.5)
+    assert torch.equal(eng.forward(a, 1, 2), eng.forward(a.clone(), 1, 2))
+    assert not torch.equal(eng.forward(a.clone(), 1, 2), indep[1])
+    # the raw entry point: a foreign token is ignored, a matching one is honoured
+    import ctypes
+    xin = indep[2].contiguous()
+    out1 = torch.empty_like(indep[3]); out2 = torch.empty_like(indep[3])
+    tok = ctypes.c_uint64(0)
+    assert eng.lib.ivit_forward_host_chained(eng._h, 3, 4, 1, ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(out1.data_ptr()),
+                                             out1.numel(), ctypes.c_uint64(0xdeadbeef), ctypes.byref(tok)) == 0
+    assert tok.value != 0 and torch.equal(out1, indep[3])
+    garbage = torch.zeros_like(indep[3])      # with a valid token the host bytes are not read at all
+    out3 = torch.empty_like(indep[4])
+    assert eng.lib.ivit_forward_host_chained(eng._h, 4, 5, 1, ctypes.c_void_p(garbage.data_ptr()), ctypes.c_void_p(out3.data_ptr()),
+                                             out3.numel(), tok, ctypes.byref(tok)) == 0
+    assert torch.equal(out3, indep[4])
+
+
 def test_concurrent_compute_from_many_threads(small):
     """Django serves /compute on concurrent threads and the reference takes no locks:
     one engine must give every thread its own correct answer.  Calls are serialised inside the

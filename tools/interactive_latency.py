@@ -35,3 +35,19 @@ for label, mk in (("node chain (%d nodes, every output returned)" % len(chain), 
         t0 = time.perf_counter(); st, out = compute_bytes(body, ctx); ts.append(time.perf_counter() - t0)
     ts.sort()
     print(f"{cfg.name} {label}: median {ts[len(ts)//2]*1e3:.2f} ms, p10 {ts[3]*1e3:.2f} ms, request {len(body)/1e6:.2f} MB, response {len(out)/1e6:.2f} MB")
+
+# ---- where a chain request spends its time (decode / each node / encode), median of 30
+from interactive_vit_amd.message import Request, Response
+body = req_chain()
+acc = {}
+for it in range(35):
+    t0 = time.perf_counter(); rq = Request(); rq.decode(body); g = rq.graph; t1 = time.perf_counter()
+    per = []
+    for n in g.order():
+        a = time.perf_counter(); n.set_pinout(ctx.get_node(n.name).compute(n.params, n.get_pinin())); per.append((n.name, time.perf_counter() - a))
+    t2 = time.perf_counter(); out = Response(g).encode(); t3 = time.perf_counter()
+    if it >= 5:
+        acc.setdefault("decode", []).append(t1 - t0); acc.setdefault("encode", []).append(t3 - t2)
+        for name, dt in per: acc.setdefault(name.split(":")[1], []).append(dt)
+med = lambda v: sorted(v)[len(v) // 2] * 1e3
+print("breakdown (ms):", ", ".join(f"{k} {med(v):.3f}" for k, v in acc.items()))
