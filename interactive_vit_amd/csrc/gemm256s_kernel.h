@@ -99,7 +99,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     const int fr = lane & 15, fq = lane >> 4;
 
     int tm, tn;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn, p.debug >= 3 ? p.debug : GEMM_GROUP_N);
     const int m0 = tm * T::BM;
     const int n0 = tn * T::BN;
 

@@ -226,12 +226,12 @@ __device__ __forceinline__ int xcd_tile(int orig, int nwg) {
 // ~8 x 8 block: 8 A row-tiles + 8 W col-tiles (~3.5 MB at K = 768) fit its 4 MiB L2, where the plain
 // n-fastest order swept all of W per row-tile and overflowed it (21 % L2 misses, 4.7x over-fetch).
 constexpr int GEMM_GROUP_N = 8;
-__device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int panel = tile / (GEMM_GROUP_N * tiles_m);
-    const int within = tile - panel * GEMM_GROUP_N * tiles_m;
-    const int width = min(GEMM_GROUP_N, tiles_n - panel * GEMM_GROUP_N);
+__device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int& tm, int& tn, int group = GEMM_GROUP_N) {
+    const int panel = tile / (group * tiles_m);
+    const int within = tile - panel * group * tiles_m;
+    const int width = min(group, tiles_n - panel * group);
     tm = within / width;
-    tn = panel * GEMM_GROUP_N + (within - tm * width);
+    tn = panel * group + (within - tm * width);
 }
 
 template <class T, bool FP8 = false>

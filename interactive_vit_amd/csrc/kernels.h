@@ -30,7 +30,7 @@ struct GemmParams {
     unsigned long long* stamps;     // microbenchmark builds only: per-block s_memrealtime stamps (nullptr in the product)
 };
 
-enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_VARIANTS = 7 };
+enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_VARIANTS = 8 };
 // fp8 (e4m3) operands, f32 accumulate: A [M,K] and W [N,K] are BYTE matrices (lda/ldw in elements = bytes)
 hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream);
 // Operand allocations must be readable up to the tile edge: A rows up to round_up(M,256)+256,

@@ -1,6 +1,7 @@
 // Instantiations of the bf16 MFMA GEMM template (gemm_kernel.h) and the per-shape tile choice.
 #include "gemm256ps_kernel.h"
 #include "gemm160x256_kernel.h"
+#include "gemm160x256w4_kernel.h"
 #include <cmath>
 
 namespace ivit {
@@ -36,6 +37,10 @@ __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_fp8_256x256x12
     gemm256s_body<0, true>(p, smem);
 }
 #ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost, and timing ablations
+__global__ __launch_bounds__(Tile160x256W4::THREADS, 1) void ivit_gemm_bf16_160x256x64_w4(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm160x256w4_body(p, smem);
+}
 __global__ __launch_bounds__(Tile160x256::THREADS, 2) void ivit_gemm_bf16_160x256x64(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm160x256_body(p, smem);
@@ -78,6 +83,7 @@ const char* gemm_variant_name(int v) {
         case GEMM_TILE_256P: return "ivit_gemm_bf16_256x256x64_pipe";
         case GEMM_TILE_256S: return "ivit_gemm_bf16_256x256x64_stag";
         case GEMM_TILE_160X256: return "ivit_gemm_bf16_160x256x64";
+        case GEMM_TILE_160X256W4: return "ivit_gemm_bf16_160x256x64_w4";
         case GEMM_TILE_256PS: return "ivit_gemm_bf16_256x256x64_persist";
     }
     return "?";
@@ -180,6 +186,7 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
             if (p.K < 2 * GEMM_BK) return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag, p, stream);
             return launch_persistent(p, stream);
         case GEMM_TILE_160X256: return launch_tile<Tile160x256>(ivit_gemm_bf16_160x256x64, p, stream);
+        case GEMM_TILE_160X256W4: return launch_tile<Tile160x256W4>(ivit_gemm_bf16_160x256x64_w4, p, stream);
 #endif
         case GEMM_TILE_256S:
 #ifdef IVIT_GEMM_ABLATIONS

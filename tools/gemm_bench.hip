@@ -136,6 +136,22 @@ int main(int argc, char** argv) {
             for (int g = 0; g < 2; ++g)
                 printf("      group %d: prologue %.2f us | K loop %.2f us | epilogue issue %.2f us | drain %.2f us\n", g,
                        seg[g][1] / cnt, seg[g][2] / cnt, seg[g][3] / cnt, seg[g][4] / cnt);
+            if (stamp_variant == GEMM_TILE_160X256W4) {   // this kernel also stamps the shader clock around its K loop
+                double cyc = 0, us = 0;
+                for (int b = 0; b < nb; ++b) {
+                    if (!hs[(size_t)b * 16]) continue;
+                    cyc += (double)(hs[(size_t)b * 16 + 10] - hs[(size_t)b * 16 + 9]);
+                    us += (double)(hs[(size_t)b * 16 + 2] - hs[(size_t)b * 16 + 1]) * 0.01;
+                }
+                double fine[4] = {0, 0, 0, 0};
+                for (int b = 0; b < nb; ++b) {
+                    if (!hs[(size_t)b * 16]) continue;
+                    for (int k = 0; k < 4; ++k) fine[k] += (double)(hs[(size_t)b * 16 + 12 + k] - hs[(size_t)b * 16 + 11 + k]);
+                }
+                printf("      K-step 4, wave 0 (shader cycles): waitcnt %.0f | barrier %.0f | 13 DMA issue %.0f | 80 MFMA + 26 ds_read %.0f\n",
+                       fine[0] / cnt, fine[1] / cnt, fine[2] / cnt, fine[3] / cnt);
+                printf("      K loop: %.0f shader cycles per block = %.0f per K-step; shader clock %.0f MHz\n", cyc / cnt, cyc / cnt / (s.K / 64), cyc / us);
+            }
             // histogram of block start times (rounds)
             int late_blocks = 0;
             for (int b = 0; b < nb; ++b) if (hs[(size_t)b * 16] && (double)(hs[(size_t)b * 16] - tmin) * 0.01 > 5.0) ++late_blocks;
