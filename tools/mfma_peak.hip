@@ -44,23 +44,28 @@ int main() {
     CK(hipMalloc(&sink, 4)); CK(hipMalloc(&dclk, 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     constexpr int NACC = 16;
+    // differential timing: (flops(N2) - flops(N1)) / (t(N2) - t(N1)) cancels launch + operand set-up time and
+    // does not depend on how many of the blocks are resident at once
     for (int rnd = 0; rnd < 2; ++rnd)
     for (int waves_per_simd : {1, 2}) {
-        for (int iters : {2000, 50000}) {
-            const int threads = 256 * waves_per_simd, blocks = 256;
-            auto kern = rnd ? mfma_loop<NACC, 1> : mfma_loop<NACC, 0>;
+        const int threads = 256 * waves_per_simd, blocks = 256;
+        auto kern = rnd ? mfma_loop<NACC, 1> : mfma_loop<NACC, 0>;
+        const int n1 = 20000, n2 = 120000;
+        float t[2]; double clk_mhz = 0;
+        for (int k = 0; k < 2; ++k) {
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, 100, sink, dclk);   // warm
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, iters, sink, dclk);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, k ? n2 : n1, sink, dclk);
             CK(hipEventRecord(e1));
             CK(hipDeviceSynchronize());
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipEventElapsedTime(&t[k], e0, e1));
             unsigned long long hc[2]; CK(hipMemcpy(hc, dclk, 16, hipMemcpyDeviceToHost));
-            const double flops = (double)blocks * (threads / 64) * iters * NACC * 16.0 * 16 * 32 * 2;
-            printf("%s operands, %d wave(s)/SIMD, %6d x %d MFMA 16x16x32 bf16 per wave: %8.3f ms  %7.1f TFLOP/s   s_memtime/s_memrealtime: %.1f MHz counter\n",
-                   rnd ? "random" : "smooth", waves_per_simd, iters, NACC, ms, flops / ms / 1e9, (double)hc[0] / ((double)hc[1] / 100.0));
+            clk_mhz = (double)hc[0] / ((double)hc[1] / 100.0);
         }
+        const double flops = (double)blocks * (threads / 64) * (double)(n2 - n1) * NACC * 16.0 * 16 * 32 * 2;
+        printf("%s operands, %d wave(s)/SIMD: %.3f -> %.3f ms for %d -> %d x %d MFMA 16x16x32 bf16 per wave:  %7.1f TFLOP/s sustained, shader clock %.0f MHz\n",
+               rnd ? "random" : "smooth", waves_per_simd, t[0], t[1], n1, n2, NACC, flops / (t[1] - t[0]) / 1e9, clk_mhz);
     }
     return 0;
 }
