@@ -25,6 +25,7 @@ __global__ void naive_rows(const bf16_t* A, int lda, const bf16_t* W, int ldw, c
 static bf16_t h_f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (bf16_t)(u >> 16); }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);   // a faulting kernel must not take the log with it
     const int Mfull = argc > 1 ? atoi(argv[1]) : 64 * 197;
     const int only_shape = argc > 2 ? atoi(argv[2]) : -1;      // -1: all shapes
     const unsigned vmask = argc > 3 ? (unsigned)strtoul(argv[3], nullptr, 0) : 0xffffffffu;
