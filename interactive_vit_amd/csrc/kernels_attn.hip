@@ -21,13 +21,14 @@
 // half (keys 32 s + 4 g .. +3, then +16).  V's 16-B chunks are XOR-swizzled by ((key >> 1) & 3) << 1,
 // which makes those reads bank-conflict free.  Softmax statistics are fp32; row max / sum are wavefront shuffles across the 4 lane groups.
 #include "kernels.h"
+#include <algorithm>
 
 namespace ivit {
 
 // Head dims: 64 (ViT-Ti/B/L: 128-B LDS rows, XOR-swizzled chunks) and 80 (ViT-H/14: 160 B of data in
 // 176-B rows - an odd number of 16-B chunks spreads rows over the banks without a swizzle; the
 // third 32-deep MFMA step of Q.K^T covers d = 64..95 with 80..95 supplied as zero fragments).
-template <int DH, int NKF>
+template <int DH, int NKF, bool ODD = false>
 struct AttLayout {
     static_assert(DH == 64 || DH == 80, "head dim 64 or 80");
     static constexpr int KEYS = NKF * 16;
@@ -35,9 +36,13 @@ struct AttLayout {
     static constexpr int CHUNKS = DH / 8;                     // 16-B chunks of data per row
     static constexpr int KSTEPS = (DH + 31) / 32;             // MFMA k-steps of Q.K^T
     static constexpr int NDB = DH / 16;                       // 16-wide output column blocks
-    static constexpr int K_BYTES = KEYS * ROW;
-    static constexpr int V_BYTES = KEYS * ROW;
-    static constexpr int LDS_BYTES = K_BYTES + V_BYTES;
+    // NKF is even (a P.V step is 32 keys).  ODD: the token count needs only NKF - 1 fragments (197 keys:
+    // 13), so the LDS images hold (NKF - 1) * 16 rows and the last fragment is never read - its scores are
+    // -inf, its probabilities 0.  At 197 keys that is the difference between two and THREE workgroups per
+    // CU (53 KB against 57 KB each), i.e. 768 heads in one round of 768 slots instead of 1.5 rounds of 512.
+    static constexpr int ROWS = (ODD ? NKF - 1 : NKF) * 16;
+    static constexpr int K_BYTES = ROWS * ROW;
+    static constexpr int LDS_BYTES = 2 * ROWS * ROW;
     static constexpr int CPR = ROW / 16;                      // 16-B chunk slots per LDS row (dh 80: 10 data + 1 pad)
     static constexpr int K_SWZ = 0, V_SWZ = 1;
     __device__ static int swz(int which, int key) { return DH == 64 ? (which == K_SWZ ? (key & 7) : (((key >> 1) & 3) << 1)) : 0; }
@@ -60,7 +65,7 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
 // not be NaN in P.V); pad slots (dh 80) are never read and stay untouched.
 template <class L>
 __device__ __forceinline__ void att_stage(char* lds, const bf16_t* src0, int ld, int N, int which, int wave, int nwaves, int lane) {
-    constexpr int SLOTS = L::KEYS * L::CPR;
+    constexpr int SLOTS = L::ROWS * L::CPR;
     constexpr int INSTR = (SLOTS + 63) / 64;
     for (int i = wave; i < INSTR; i += nwaves) {
         const int slot = i * 64 + lane;
@@ -76,9 +81,9 @@ __device__ __forceinline__ void att_stage(char* lds, const bf16_t* src0, int ld,
     }
 }
 
-template <int DH, int NKF, bool PROBS>
+template <int DH, int NKF, bool ODD, bool PROBS>
 __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
-    using L = AttLayout<DH, NKF>;
+    using L = AttLayout<DH, NKF, ODD>;
     constexpr int ATT_DH = DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
         f32x4 s[NKF];
 #pragma unroll
         for (int f = 0; f < NKF; ++f) {
+            if (ODD && f == NKF - 1) { s[f] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }   // no such rows in LDS: masked to -inf below
             const int key = f * 16 + fr;
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -213,7 +219,8 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
                 const char* hi = v_lds + L::v_off(key_lo + 16, chunk) + (tp & 1) * 8;
                 union { bf16x8 v; bf16x4 h2[2]; } vf;
                 vf.h2[0] = lds_read_tr16(lo);
-                vf.h2[1] = lds_read_tr16(hi);
+                if (ODD && st == NKF / 2 - 1) vf.h2[1] = bf16x4{0, 0, 0, 0};   // the fragment that is not in LDS: its P is exactly 0
+                else vf.h2[1] = lds_read_tr16(hi);
                 o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, o[d], 0, 0, 0);
             }
         }
@@ -246,26 +253,31 @@ bool attention_supported(int tokens, int head_dim) {
     return false;
 }
 
-template <int DH, int NKF, bool PROBS>
+template <int DH, int NKF, bool ODD, bool PROBS>
 static hipError_t launch_nkf_impl(const AttnParams& p, hipStream_t stream) {
-    using L = AttLayout<DH, NKF>;
+    using L = AttLayout<DH, NKF, ODD>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<DH, NKF, PROBS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<DH, NKF, ODD, PROBS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int blocks = ceil_div(p.tokens, 16);
-    const int waves = blocks < 8 ? blocks : 8;                    // every wave gets at least one 16-query block
+    // every wave gets at least one 16-query block.  (Measured at 197 keys, three 5-wave workgroups per CU -
+    // which the 53-KiB ODD image allows - against two of 7-8 waves: 0.333 vs 0.307 ms per 12 launches; the
+    // launch moves 58 + 19 MB in 25 us and is bound by that, not by the 1.5-round grid.)
+    const int waves = std::min(8, blocks);
     dim3 grid(1, p.heads, p.batch);
-    hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, PROBS>), grid, dim3(waves * 64), L::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, ODD, PROBS>), grid, dim3(waves * 64), L::LDS_BYTES, stream, p);
     return hipGetLastError();
 }
 
 template <int DH, int NKF>
 static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
-    return p.probs ? launch_nkf_impl<DH, NKF, true>(p, stream) : launch_nkf_impl<DH, NKF, false>(p, stream);
+    const bool odd = ceil_div(p.tokens, 16) == NKF - 1;   // the last of the NKF fragments holds no key at all
+    if (odd) return p.probs ? launch_nkf_impl<DH, NKF, true, true>(p, stream) : launch_nkf_impl<DH, NKF, true, false>(p, stream);
+    return p.probs ? launch_nkf_impl<DH, NKF, false, true>(p, stream) : launch_nkf_impl<DH, NKF, false, false>(p, stream);
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
