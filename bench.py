@@ -98,6 +98,11 @@ def cpu_baseline(cfg, sd, seconds: float):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the result): everything else that the libraries underneath print
+    # there (RCCL's version banner, libdrm notices) is sent to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -262,7 +267,8 @@ def main():
                        "weights": "random init N(0,0.02^2) seed 0"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -25,8 +25,9 @@ def test_bench_runs_under_torchrun_with_rccl():
            "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch-per-gpu", "8"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1, out_lines          # RCCL's banner etc. must not reach stdout: ONE line, the result
+    d = json.loads(out_lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["collective"] == "all_gather_into_tensor over nccl (RCCL), 1 per step"
     assert d["parity"]["gathered_equals_local"] is True
@@ -38,8 +39,8 @@ def test_bench_json_contract_single_gpu():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
