@@ -1,7 +1,11 @@
 // Instantiations of the bf16 MFMA GEMM template (gemm_kernel.h) and the per-shape tile choice.
-#include "gemm256ps_kernel.h"
-#include "gemm160x256_kernel.h"
-#include "gemm160x256w4_kernel.h"
+#include "gemm256s_kernel.h"
+#ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost (csrc/study/)
+#include "study/gemm256p_kernel.h"
+#include "study/gemm256ps_kernel.h"
+#include "study/gemm160x256_kernel.h"
+#include "study/gemm160x256w4_kernel.h"
+#endif
 #include <cmath>
 
 namespace ivit {

@@ -18,7 +18,7 @@
 // 8 waves = 2 (M) x 4 (N); a wave owns 80 x 64 = 5 x 4 MFMA fragments (80 accumulator VGPRs); the
 // fragment reads of the second 32-deep half of a K-step are issued before the MFMAs of the first.
 #pragma once
-#include "gemm_kernel.h"
+#include "../gemm_kernel.h"
 
 namespace ivit {
 

@@ -20,7 +20,7 @@
 // DMA goes through buffer descriptors (scalar K / piece offsets, out-of-range offsets past the end
 // of K move no data but keep the vmcnt arithmetic constant), as in gemm160x256_kernel.h.
 #pragma once
-#include "gemm256s_kernel.h"   // IVIT_STAMP
+#include "../gemm256s_kernel.h"   // IVIT_STAMP
 
 namespace ivit {
 

@@ -14,7 +14,8 @@
 // LDS buffer sets alternate with the running K-tile counter g (not the tile-local index), so an odd
 // K-tile count per output tile is fine.  Requires K >= 128 (two K-tiles).
 #pragma once
-#include "gemm256s_kernel.h"
+#include "../gemm256s_kernel.h"
+#include "gemm256p_kernel.h"
 
 namespace ivit {
 
