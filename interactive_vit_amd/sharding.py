@@ -42,10 +42,13 @@ def pack_outputs(logits: torch.Tensor, cls: torch.Tensor, out: Optional[torch.Te
 
 
 def all_gather_outputs(local: torch.Tensor, total: int, group=None,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, async_op: bool = False):
     """ONE collective: every rank ends with the [total, width] outputs of the whole batch, in image
     order.  Equal shards use ``all_gather_into_tensor`` directly; ragged shards are padded to the
-    largest shard for the collective and compacted afterwards (still one collective)."""
+    largest shard for the collective and compacted afterwards (still one collective).
+
+    ``async_op=True`` (equal shards, ``out`` given): returns the work handle instead of the tensor, so
+    that the collective overlaps the next batch's compute; ``out`` is valid after ``handle.wait()``."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     sizes = shard_sizes(total, world)
@@ -54,8 +57,12 @@ def all_gather_outputs(local: torch.Tensor, total: int, group=None,
     if len(set(sizes)) == 1:
         if out is None:
             out = torch.empty((total, width), dtype=local.dtype, device=local.device)
+        if async_op:
+            return dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=True)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out
+    if async_op:
+        raise ValueError("async_op needs equal shards")
     big = max(sizes)
     padded = torch.zeros((big, width), dtype=local.dtype, device=local.device)
     padded[:local.shape[0]].copy_(local)
