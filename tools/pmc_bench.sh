@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 be
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.log 2>&1
 cp $OUT/stats/*/*_kernel_stats.csv profiles/${TAG}_kernel_stats.csv
-tail -1 $OUT/stats.log > profiles/${TAG}_bench_under_rocprof.json || true
+grep "^{\"metric\"" $OUT/stats.log | tail -1 > profiles/${TAG}_bench_under_rocprof.json || true
 python3 - "$OUT" "$TAG" "$*" <<'PY'
 import csv, glob, json, sys, collections, re
 out, tag, extra = sys.argv[1], sys.argv[2], sys.argv[3]
