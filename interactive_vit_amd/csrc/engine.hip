@@ -126,9 +126,10 @@ struct ivit_engine {
     hipStream_t own_stream = nullptr;
     // sub-batch concurrency: memory-bound kernels (LayerNorm, attention staging, GEMM epilogues) of
     // one half of the batch overlap the MFMA-bound main loops of the other half
-    int split = 1, split_min_batch = 16;
-    hipStream_t aux_stream[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    int split = 1, split_min_batch = 32;   // IVIT_SPLIT (helps ViT-B/16 from B = 32 up, hurts at B = 16 and on ViT-L / ViT-H)
+    static constexpr int MAX_SPLIT = 4;
+    hipStream_t aux_stream[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_SPLIT] = {nullptr, nullptr, nullptr, nullptr};
     // The activation workspaces are shared by every call, and calls may arrive on different streams
     // (the host-buffer entry uses own_stream, the device entry the caller's): each call's stream
     // first waits for the event the previous call recorded when it finished with the workspaces.
@@ -245,8 +246,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         e->split = sp ? atoi(sp) : 1;
         const char* gr = getenv("IVIT_GRAPHS");
         e->graphs_on = !(gr && atoi(gr) == 0);
-        if (e->split < 1 || e->split > 2) e->split = 1;
-        for (int i = 0; i < 2; ++i) {
+        if (e->split < 1 || e->split > ivit_engine::MAX_SPLIT) e->split = 1;
+        for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
             if (hipStreamCreateWithFlags(&e->aux_stream[i], hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("aux stream/event creation failed"); }
         }
@@ -320,7 +321,7 @@ extern "C" void ivit_destroy(ivit_engine* e) {
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->map_buf) (void)hipFree(e->map_buf);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
     }
@@ -644,19 +645,21 @@ static int forward_locked(ivit_engine* e, int begin, int end, int B, const float
     const int L = e->cfg.layers;
     const bool has_layers = (begin < ST_LAYER0 + L) && (end > ST_LAYER0);
     if (e->split < 2 || B < e->split_min_batch || !has_layers) return forward_one(e, ws_slice(e, 0), begin, end, B, in, out, cls_out, st);
-    // fork: two sub-batches on two streams; join back into the caller's stream
+    // fork: `split` sub-batches on as many streams; join back into the caller's stream
     const int64_t n_in = shape_elems(&e->cfg, begin, 0), n_out = shape_elems(&e->cfg, end - 1, 1);
     HIP_TRY(hipEventRecord(e->ev_fork, st));
-    const int half = (B + 1) / 2;
-    for (int i = 0; i < 2; ++i) {
-        const int b0 = i * half, bn = (i == 0) ? half : B - half;
+    const int parts = e->split, base = B / parts, rem = B % parts;
+    int b0 = 0;
+    for (int i = 0; i < parts; ++i) {
+        const int bn = base + (i < rem ? 1 : 0);
         hipStream_t s = e->aux_stream[i];
         HIP_TRY(hipStreamWaitEvent(s, e->ev_fork, 0));
         if (forward_one(e, ws_slice(e, b0), begin, end, bn, in + (size_t)b0 * n_in, out + (size_t)b0 * n_out,
                         cls_out ? cls_out + (size_t)b0 * e->D : nullptr, s)) return 1;
         HIP_TRY(hipEventRecord(e->ev_join[i], s));
+        b0 += bn;
     }
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(st, e->ev_join[i], 0));
+    for (int i = 0; i < parts; ++i) HIP_TRY(hipStreamWaitEvent(st, e->ev_join[i], 0));
     return 0;
 }
 
