@@ -297,6 +297,7 @@ def main():
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     eng.close()
     if use_dist:
+        dist.barrier()     # rank 0's parity / instrumented pass runs after the timed loop: leave together
         dist.destroy_process_group()
 
 
