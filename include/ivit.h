@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define IVIT_ABI_VERSION 3
+#define IVIT_ABI_VERSION 4
 
 #define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
 #define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
@@ -104,6 +104,17 @@ int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end, int batch,
 int ivit_forward_host_chained(ivit_engine* e, int stage_begin, int stage_end, int batch,
                               const float* in, float* out, int64_t out_capacity,
                               uint64_t in_token, uint64_t* out_token);
+
+/* The `<model>:preprocess` node: what the reference's model plugin does to a raw image with its weights'
+ * preset (static/models/vgg16.py:40-42, `weights.transforms()`): `in` is [batch,3,height,width] f32 in
+ * [0,1], any size; the shorter side is resized to image*256/224 (antialiased bilinear, ATen's
+ * upsample_bilinear2d_aa weights), the centre image x image square is cropped and normalised with the
+ * ImageNet mean / std - i.e. the result is what the `transform` stage gives for an image x image input and
+ * feeds `conv_proj`.  Host form: *out_token (optional) names the resident copy as in
+ * ivit_forward_host_chained.  Device form: enqueued on `stream`, no synchronisation. */
+int ivit_preprocess_host(ivit_engine* e, int batch, const float* in, int height, int width,
+                         float* out, int64_t out_capacity, uint64_t* out_token);
+int ivit_preprocess(ivit_engine* e, int batch, const void* in, int height, int width, void* out, void* stream);
 
 /* Device-pointer form (benchmark / chained nodes): `in` and `out` are device f32 buffers on the
  * engine's device, work is enqueued on `stream` (a hipStream_t; NULL = the null stream) and the

@@ -152,6 +152,8 @@ struct ivit_engine {
     float *x = nullptr, *clsf = nullptr, *ext_in = nullptr, *ext_out = nullptr, *upload = nullptr;
     int64_t ext_elems = 0, upload_elems = 0;
     float* map_buf = nullptr;     // attention-map staging for the host path (grown on demand)
+    float* pre_buf = nullptr;     // raw-image staging of ivit_preprocess_host (grown on demand)
+    size_t pre_bytes = 0;
     size_t map_bytes = 0;
     // hipGraph cache of the host path: a small-batch forward is ~90 launches of microsecond kernels
     // (launch-bound), and its buffers (ext_in / ext_out / workspaces) never move, so the launch
@@ -320,6 +322,7 @@ extern "C" void ivit_destroy(ivit_engine* e) {
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->map_buf) (void)hipFree(e->map_buf);
+    if (e->pre_buf) (void)hipFree(e->pre_buf);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
@@ -801,6 +804,52 @@ extern "C" int ivit_attention_map_host(ivit_engine* e, int layer, int batch, con
     HIP_TRY(hipMemcpyAsync(out, e->map_buf, need, hipMemcpyDeviceToHost, st));
     if (ws_release(e, st)) return 1;
     HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ---- preprocess: [B,3,H,W] in [0,1], any size -> what the `transform` stage gives for an S x S image
+static int preprocess_resize(const ivit_engine* e) { return (e->cfg.image * 256 + 112) / 224; }   // 224 -> 256, 384 -> 439
+
+extern "C" int ivit_preprocess(ivit_engine* e, int batch, const void* in, int height, int width, void* out, void* stream) {
+    if (!e || !in || !out) return fail("ivit_preprocess: null argument");
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    if (height < 1 || width < 1 || height > 16384 || width > 16384) return fail("image size %dx%d outside 1..16384", height, width);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(e, PC_OTHER, st, 0.0, 4.0 * batch * 3 * ((double)height * width + (double)e->cfg.image * e->cfg.image));
+    HIP_TRY(launch_preprocess((const float*)in, height, width, (float*)out, batch, e->cfg.image, preprocess_resize(e), st));
+    return 0;
+}
+
+extern "C" int ivit_preprocess_host(ivit_engine* e, int batch, const float* in, int height, int width, float* out, int64_t out_capacity,
+                                    uint64_t* out_token) {
+    if (!e || !in || !out) return fail("ivit_preprocess_host: null argument");
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    if (height < 1 || width < 1 || height > 16384 || width > 16384) return fail("image size %dx%d outside 1..16384", height, width);
+    const int S = e->cfg.image;
+    const int64_t n_in = (int64_t)batch * 3 * height * width, n_out = (int64_t)batch * 3 * S * S;
+    if (n_out > out_capacity) return fail("ivit_preprocess_host: output needs %lld floats, capacity is %lld", (long long)n_out, (long long)out_capacity);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->own_stream;
+    const size_t need = (size_t)n_in * 4;
+    if (need > e->pre_bytes) {
+        if (e->pre_buf) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(e->pre_buf); e->pre_buf = nullptr; e->pre_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&e->pre_buf, need));
+        e->pre_bytes = need;
+    }
+    if (ws_acquire(e, st)) return 1;
+    e->resident_token = 0;
+    HIP_TRY(hipMemcpyAsync(e->pre_buf, in, need, hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_preprocess(e->pre_buf, height, width, e->ext_out, batch, S, preprocess_resize(e), st));
+    HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    if (ws_release(e, st)) return 1;
+    HIP_TRY(hipStreamSynchronize(st));
+    // the result stays resident like any host-path output: `conv_proj` can take it without an upload
+    e->resident_token = ++e->token_counter;
+    e->resident_elems = n_out;
+    if (out_token) *out_token = e->resident_token;
     return 0;
 }
 

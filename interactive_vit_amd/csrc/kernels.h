@@ -56,6 +56,8 @@ bool attention_supported(int tokens, int head_dim);
 // ---------------------------------------------------------------- misc (kernels_misc.hip)
 // (x - mean[c]) / std[c] on [B,3,S,S] f32
 hipError_t launch_transform(const float* in, float* out, int batch, int image, hipStream_t s);
+// [B,3,H,W] in [0,1] -> [B,3,image,image]: antialiased bilinear resize of the shorter side to `resize`, centre crop, normalise
+hipError_t launch_preprocess(const float* in, int H, int W, float* out, int batch, int image, int resize, hipStream_t s);
 // f32 image -> bf16 unfold matrix [B*Np, kpad] (columns >= 3p^2 zero); normalise fuses the transform
 hipError_t launch_unfold(const float* in, bf16_t* out, int batch, int image, int patch, int kpad,
                          int normalise, hipStream_t s);

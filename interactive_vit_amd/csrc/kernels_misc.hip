@@ -38,6 +38,65 @@ hipError_t launch_transform(const float* in, float* out, int batch, int image, h
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------- preprocess
+// The classification preset of the reference's model plugin (static/models/vgg16.py:40-42 applies
+// `weights.transforms()`): resize the shorter side to R with the antialiased bilinear filter, centre-crop
+// S x S, normalise.  Weights as in ATen's upsample_bilinear2d_aa (align_corners = false): scale = in / out,
+// support = max(scale, 1), centre = scale (i + 0.5), taps [int(centre - support + 0.5), int(centre + support
+// + 0.5)) clipped to the image, triangle weights (1 - |(j - centre + 0.5) / max(scale, 1)|)+, normalised.
+// One thread per output pixel, both dimensions filtered at once (ATen filters W then H: same sum, other
+// rounding order).
+__device__ __forceinline__ void aa_taps(int out_i, float scale, int in_size, int& first, int& count, float& support, float& centre) {
+    support = scale >= 1.0f ? scale : 1.0f;
+    centre = scale * ((float)out_i + 0.5f);
+    first = max((int)(centre - support + 0.5f), 0);
+    count = min((int)(centre + support + 0.5f), in_size) - first;
+}
+__device__ __forceinline__ float aa_weight(int j, int first, float centre, float scale) {
+    const float inv = scale >= 1.0f ? 1.0f / scale : 1.0f;
+    const float x = ((float)(j + first) - centre + 0.5f) * inv;
+    const float a = fabsf(x);
+    return a < 1.0f ? 1.0f - a : 0.0f;
+}
+
+__global__ void ivit_preprocess(const float* __restrict__ in, int H, int W, float* __restrict__ out, int S, int RH, int RW,
+                                int top, int left, int batch) {
+    const float sh = (float)H / (float)RH, sw = (float)W / (float)RW;
+    const int64_t total = (int64_t)batch * 3 * S * S;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S), y = (int)((i / S) % S);
+        const int c = (int)((i / ((int64_t)S * S)) % 3);
+        const int64_t img = i / ((int64_t)3 * S * S);
+        int y0, ny, x0, nx; float suph, ch, supw, cw;
+        aa_taps(y + top, sh, H, y0, ny, suph, ch);
+        aa_taps(x + left, sw, W, x0, nx, supw, cw);
+        float wxs = 0.f, wys = 0.f;
+        for (int j = 0; j < nx; ++j) wxs += aa_weight(j, x0, cw, sw);
+        for (int j = 0; j < ny; ++j) wys += aa_weight(j, y0, ch, sh);
+        const float* src = in + (img * 3 + c) * (int64_t)H * W;
+        float acc = 0.f;
+        for (int jy = 0; jy < ny; ++jy) {
+            const float wy = aa_weight(jy, y0, ch, sh) / wys;
+            const float* row = src + (int64_t)(y0 + jy) * W + x0;
+            float r = 0.f;
+            for (int jx = 0; jx < nx; ++jx) r += (aa_weight(jx, x0, cw, sw) / wxs) * row[jx];
+            acc += wy * r;
+        }
+        out[i] = (acc - c_mean[c]) / c_std[c];
+    }
+}
+
+hipError_t launch_preprocess(const float* in, int H, int W, float* out, int batch, int image, int resize, hipStream_t s) {
+    if (H < 1 || W < 1 || resize < image) return hipErrorInvalidValue;
+    // torchvision: shorter side -> resize, longer side -> int(resize * long / short); crop offsets int(round((r - S) / 2))
+    int rh, rw;
+    if (H <= W) { rh = resize; rw = (int)((int64_t)resize * W / H); } else { rw = resize; rh = (int)((int64_t)resize * H / W); }
+    const int top = (int)lrintf((float)(rh - image) / 2.0f), left = (int)lrintf((float)(rw - image) / 2.0f);
+    const int64_t total = (int64_t)batch * 3 * image * image;
+    hipLaunchKernelGGL(ivit_preprocess, dim3(ew_grid(total)), dim3(EW_THREADS), 0, s, in, H, W, out, image, rh, rw, top, left, batch);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------- unfold (im2col)
 // One thread produces 8 consecutive k of one patch row n: 16 B of bf16.  For p % 8 == 0 the 8
 // sources are 8 consecutive pixels of one image row (two float4 loads); otherwise each element is

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libivit.so")
 ABI_SYMBOLS = (
     "ivit_abi_version", "ivit_build_info", "ivit_last_error", "ivit_stage_count", "ivit_stage_shape",
     "ivit_unfold_offset", "ivit_create", "ivit_destroy", "ivit_set_weight", "ivit_weights_ready",
-    "ivit_forward_host", "ivit_forward_host_chained", "ivit_forward_device", "ivit_attention_map", "ivit_attention_map_host",
+    "ivit_forward_host", "ivit_forward_host_chained", "ivit_forward_device", "ivit_preprocess", "ivit_preprocess_host", "ivit_attention_map", "ivit_attention_map_host",
     "ivit_fp8_calibrate", "ivit_fp8_scales", "ivit_debug_unfold", "ivit_profile_enable",
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
 )
@@ -36,7 +36,7 @@ class IvitConfigC(ctypes.Structure):
                 ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PRECISIONS = {"bf16": 0, "fp8": 1}
 
 
@@ -75,6 +75,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_weights_ready.argtypes = [c_p]
         lib.ivit_forward_host.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64]
         lib.ivit_forward_host_chained.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        lib.ivit_preprocess_host.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_i64, ctypes.POINTER(ctypes.c_uint64)]
+        lib.ivit_preprocess.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_p]
         lib.ivit_forward_device.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
         lib.ivit_attention_map.argtypes = [c_p, c_i, c_i, c_p, c_p, c_p]
         lib.ivit_attention_map_host.argtypes = [c_p, c_i, c_i, c_p, c_p, c_i64]
@@ -250,7 +252,35 @@ class Engine:
                                                 ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
         return out
 
+    def preprocess(self, x: torch.Tensor) -> torch.Tensor:
+        """Raw image(s) [3,H,W] / [B,3,H,W] in [0,1], any size -> the normalised [.., 3,S,S] input of
+        ``conv_proj`` (include/ivit.h: ivit_preprocess*).  CPU in -> CPU out, CUDA in -> CUDA out."""
+        if x.dim() not in (3, 4) or x.shape[-3] != 3:
+            raise EngineError(f"{self.cfg.name}:preprocess expects [3,H,W] or [B,3,H,W], got {list(x.shape)}")
+        batched = x.dim() == 4
+        batch = int(x.shape[0]) if batched else 1
+        h, w = int(x.shape[-2]), int(x.shape[-1])
+        s_ = self.cfg.image
+        full = (batch, 3, s_, s_) if batched else (3, s_, s_)
+        xin = x.detach().to(torch.float32).contiguous()
+        if x.device.type == "cpu":
+            out = torch.empty(full, dtype=torch.float32, pin_memory=self._pin)
+            tok = ctypes.c_uint64(0)
+            self._check(self.lib.ivit_preprocess_host(self._h, batch, ctypes.c_void_p(xin.data_ptr()), h, w,
+                                                      ctypes.c_void_p(out.data_ptr()), out.numel(), ctypes.byref(tok)))
+            self._last_out = (weakref.ref(out), out._version, tok.value)
+            return out
+        if x.device.type != "cuda" or (x.device.index or 0) != self.device:
+            raise EngineError(f"input lives on {x.device}, engine on cuda:{self.device}")
+        out = torch.empty(full, dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        self._check(self.lib.ivit_preprocess(self._h, batch, ctypes.c_void_p(xin.data_ptr()), h, w,
+                                             ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
+        return out
+
     def run_node(self, suffix: str, x: torch.Tensor) -> torch.Tensor:
+        if suffix == "preprocess":
+            return self.preprocess(x)
         if suffix == "forward":
             return self.forward(x, 0, len(self.stages))
         if suffix.endswith(".attn"):

@@ -5,7 +5,9 @@
 Nodes (``<name>:`` prefix): ``transform``, ``conv_proj``, ``tokens``, ``encoder.layers.<i>``
 (residual-inclusive: the server graph cannot fan out), ``encoder.ln``, ``cls``,
 ``heads`` - a linear chain that ends in a client-side ``category`` node - the standalone
-``forward`` node (whole model in one launch sequence), and ``encoder.layers.<i>.attn`` inspectors
+``forward`` node (whole model in one launch sequence), the standalone ``preprocess`` node (raw image of
+any size -> resize / centre crop / normalise, the classification preset of vgg16.py:40-42; use it in place
+of ``transform``), and ``encoder.layers.<i>.attn`` inspectors
 (``[N,D]`` residual stream in, attention probabilities ``[heads,N,N]`` out - a ``[C,H,W]`` tensor the
 client's MultiView displays).  Every node takes one input "o" and gives
 one output "o"; images are unbatched ``[3,S,S]`` in the interactive path, a leading batch axis is
@@ -93,7 +95,9 @@ def make_vit_model_class(ModelBase, PinoutCls):
             # the chain, the fused whole model, and one attention-map inspector per encoder layer
             # ([N,D] -> [heads,N,N]; put it in place of layer i at the end of a shorter chain: the
             # server graph cannot fan out)
-            return self.chain_node_names() + [self.prefix() + "forward"] + self.attn_node_names()
+            # ... and `preprocess`, the raw-image front end (any [3,H,W] -> what `transform` gives for [3,S,S]):
+            # put it in place of `transform` when the image does not come from a client-side Resize node
+            return self.chain_node_names() + [self.prefix() + "forward", self.prefix() + "preprocess"] + self.attn_node_names()
 
         def generate_graph_json(self) -> Dict:
             """Chain graph in the client's schema (graph.js:700-758), laid out exactly like
@@ -120,7 +124,7 @@ def make_vit_model_class(ModelBase, PinoutCls):
             x = pinin.get("o")
             assert x is not None
             suffix = node_name.removeprefix(self.prefix())
-            if suffix != "forward" and suffix not in self._suffixes and node_name not in self.attn_node_names():
+            if suffix not in ("forward", "preprocess") and suffix not in self._suffixes and node_name not in self.attn_node_names():
                 raise KeyError(node_name)
             with torch.no_grad():
                 y = self.backend.run_node(suffix, x)
@@ -134,6 +138,7 @@ def make_vit_model_class(ModelBase, PinoutCls):
             c = self.cfg
             detail = {
                 "transform": "normalise (ImageNet mean/std)",
+                "preprocess": f"resize {(c.image * 256 + 112) // 224} (antialiased) &rarr; centre crop {c.image} &rarr; normalise",
                 "conv_proj": f"patch embed {c.patch}x{c.patch} &rarr; [{c.patches},{c.dim}]",
                 "tokens": f"[CLS] + position &rarr; [{c.tokens},{c.dim}]",
                 "encoder.ln": "LayerNorm",

@@ -114,6 +114,29 @@ def transform(x: torch.Tensor) -> torch.Tensor:
     return (x - mean) / std
 
 
+def preprocess_resize(cfg) -> int:
+    """Shorter-side target of the preset: 256 for a 224 crop, scaled with the model's image size."""
+    return (cfg.image * 256 + 112) // 224
+
+
+def preprocess(x: torch.Tensor, cfg) -> torch.Tensor:
+    """The classification preset the reference's model plugin applies to a raw image
+    (static/models/vgg16.py:40-42, ``weights.transforms()`` = torchvision ImageClassification):
+    [B,3,H,W] in [0,1], any size -> antialiased bilinear resize of the shorter side, centre crop
+    S x S, normalise.  Resize arithmetic is ATen's (torch.nn.functional.interpolate, antialias=True);
+    sizes and crop offsets follow torchvision's functional resize / center_crop."""
+    b, c, h, w = x.shape
+    r = preprocess_resize(cfg)
+    if h <= w:
+        nh, nw = r, int(r * w / h)
+    else:
+        nh, nw = int(r * h / w), r
+    y = torch.nn.functional.interpolate(x.to(torch.float32), size=(nh, nw), mode="bilinear", antialias=True, align_corners=False)
+    s_ = cfg.image
+    top, left = int(round((nh - s_) / 2.0)), int(round((nw - s_) / 2.0))
+    return transform(y[:, :, top:top + s_, left:left + s_]).to(x.dtype)
+
+
 def conv_proj(x: torch.Tensor, sd, cfg, emulate: bool = False) -> torch.Tensor:
     """Patch embedding as unfold + GEMM: [B,3,S,S] -> [B,Np,D]."""
     dt = x.dtype
@@ -296,6 +319,8 @@ def run_node(suffix: str, x: torch.Tensor, sd, cfg, emulate: bool = False) -> to
     """One node on a BATCHED input (leading B axis)."""
     if suffix == "transform":
         return transform(x)
+    if suffix == "preprocess":
+        return preprocess(x, cfg)
     if suffix == "conv_proj":
         return conv_proj(x, sd, cfg, emulate)
     if suffix == "tokens":
@@ -336,7 +361,7 @@ def forward(x: torch.Tensor, sd, cfg, keep: bool = False, emulate: bool = False)
 
 
 # unbatched ranks of each node's input, to accept both [3,S,S] and [B,3,S,S] style tensors
-INPUT_RANK = {"transform": 3, "conv_proj": 3, "tokens": 2, "encoder.ln": 2, "cls": 2, "heads": 1,
+INPUT_RANK = {"transform": 3, "preprocess": 3, "conv_proj": 3, "tokens": 2, "encoder.ln": 2, "cls": 2, "heads": 1,
               "forward": 3}
 
 

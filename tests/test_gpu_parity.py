@@ -358,6 +358,35 @@ def test_chained_host_calls_consume_the_resident_copy(small):
     assert torch.equal(out3, indep[4])
 
 
+def test_preprocess_node_matches_oracle(small):
+    """`<model>:preprocess`: raw image of any size -> antialiased resize, centre crop,
+    normalise.  Oracle = ATen's own antialiased bilinear (torch.nn.functional.interpolate) + torchvision's
+    size / offset rules; the kernel sums the two filter dimensions at once, so agreement is to f32 round-off."""
+    from oracle import vit_oracle
+    from interactive_vit_amd.engine import EngineError
+    cfg, sd, eng = small
+    s_ = cfg.image
+    g = torch.Generator().manual_seed(11)
+    for (h, w) in ((s_ * 2 + 5, s_ * 3 + 1), (s_ * 3, s_ * 2), (s_, s_), (s_ + 7, s_ * 8), (s_ * 256 // 224 + 1, s_ * 256 // 224 + 1)):
+        x = torch.rand((3, h, w), generator=g)
+        ref = vit_oracle.preprocess(x[None].double(), cfg)[0]
+        got = eng.run_node("preprocess", x)
+        assert got.shape == (3, s_, s_) and got.dtype == torch.float32
+        err = float((got.double() - ref).abs().max())
+        assert err <= 2e-5, f"{h}x{w}: max abs err {err:.2e}"
+        dev = eng.run_node("preprocess", x.cuda()).cpu()
+        assert torch.equal(dev, got), "host and device entry points differ"
+    # batched, and chained into conv_proj without an upload (the result stays resident like any host output)
+    xb = torch.rand((3, 3, s_ * 2, s_ * 2 + 9), generator=g)
+    pb = eng.run_node("preprocess", xb)
+    assert torch.allclose(pb.double(), vit_oracle.preprocess(xb.double(), cfg), atol=2e-5)
+    one = eng.run_node("preprocess", xb[0])
+    chained = eng.run_node("conv_proj", one)
+    assert torch.equal(chained, eng.run_node("conv_proj", one.clone()))
+    with pytest.raises(EngineError):
+        eng.run_node("preprocess", torch.rand((4, s_, s_)))
+
+
 def test_concurrent_compute_from_many_threads(small):
     """Django serves /compute on concurrent threads and the reference takes no locks:
     one engine must give every thread its own correct answer.  Calls are serialised inside the

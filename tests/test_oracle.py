@@ -177,3 +177,31 @@ def test_vit_tiny_node_graph_matches_reference_run():
         assert torch.allclose(samples, torch.tensor(rec["samples"]), rtol=1e-4, atol=1e-5 * max(1.0, rec["max_abs"])), rec["endpoint"]
         assert abs(float(flat.abs().max()) - rec["max_abs"]) <= 1e-4 * max(1.0, rec["max_abs"])
     assert torch.allclose(blocks[-1][2], torch.tensor(VGOLD["logits"]), rtol=1e-4, atol=1e-5)
+
+
+def test_preprocess_oracle_is_the_torchvision_preset():
+    """`preprocess` = resize shorter side (antialiased bilinear) -> centre crop S -> normalise, the
+    ImageClassification preset of the reference's model plugin (vgg16.py:40-42).  torchvision is not
+    installed here, so its size / offset arithmetic is pinned by known cases and the resize by properties."""
+    from interactive_vit_amd.vit_config import VARIANTS
+    from oracle import vit_oracle
+    cfg = VARIANTS["vit_b_16"]
+    assert vit_oracle.preprocess_resize(cfg) == 256 and vit_oracle.preprocess_resize(VARIANTS["vit_l_16_384"]) == 439
+    g = torch.Generator().manual_seed(5)
+    # a constant image stays constant through the (normalised-weight) resize: output = (c - mean) / std
+    x = torch.full((1, 3, 300, 500), 0.25)
+    y = vit_oracle.preprocess(x, cfg)
+    assert y.shape == (1, 3, 224, 224)
+    ref = vit_oracle.transform(torch.full((1, 3, 224, 224), 0.25))
+    assert torch.allclose(y, ref, atol=1e-6)
+    # already 256 on the shorter side and square: no resampling at all, the crop offset is (256 - 224) / 2 = 16
+    x = torch.rand((2, 3, 256, 256), generator=g)
+    y = vit_oracle.preprocess(x, cfg)
+    assert torch.allclose(y, vit_oracle.transform(x[:, :, 16:240, 16:240]), atol=1e-6)
+    # portrait and landscape go through the same code with the roles of H and W swapped
+    x = torch.rand((1, 3, 333, 517), generator=g)
+    a = vit_oracle.preprocess(x, cfg)
+    b = vit_oracle.preprocess(x.transpose(2, 3).contiguous(), cfg).transpose(2, 3)
+    assert torch.allclose(a, b, atol=1e-6)
+    # unbatched form through the node dispatcher
+    assert torch.equal(vit_oracle.run_node_any("preprocess", x[0], None, cfg), a[0])

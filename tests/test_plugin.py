@@ -32,7 +32,7 @@ def plugin(tmp_path):
 def test_registration_and_graph_file(plugin):
     cfg, sd, vit, ctx, base = plugin
     names = vit.list_node_names()
-    assert names == ([f"{cfg.name}:{s}" for s in node_suffixes(cfg)] + [f"{cfg.name}:forward"]
+    assert names == ([f"{cfg.name}:{s}" for s in node_suffixes(cfg)] + [f"{cfg.name}:forward", f"{cfg.name}:preprocess"]
                      + [f"{cfg.name}:encoder.layers.{i}.attn" for i in range(cfg.layers)])
     assert sorted(ctx.nodes) == sorted(names)
     assert all("/" not in n for n in names)             # node names are URL path segments (urls.py:12-13)
