@@ -106,17 +106,18 @@ static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream)
     return hipGetLastError();
 }
 
-// Tile choice, from tools/gemm_bench on MI355X (ViT-B/16 shapes, M = 12608; TFLOP/s, batched epilogue):
-//                       128x128   160x128   256x256 staggered   256x256 persistent
-//   N=2304 K= 768 (qkv)   ~640       717          758                 745
-//   N= 768 K= 768 (proj)  ~370       528          435                 402
-//   N=3072 K= 768 (mlp1)  ~600       726          686                 671      (with the GELU epilogue)
-//   N= 768 K=3072 (mlp2)  ~660       912          809                 744
-// Both families sit on the same wall: the per-CU L2->LDS path delivers ~55-60 GB/s, which caps a
-// 160x128 tile (71 FLOP/B) near 1000 TFLOP/s; the 256x256 tile (128 FLOP/B) has the headroom but one
-// workgroup per CU, so its epilogue (13 us for an f32 residual tile, in-kernel stamps) is not hidden
-// by another workgroup's main loop and its grid quantises worse.  It wins only on wide, bf16-output
-// shapes with >= 2 rounds of tiles.
+// Tile choice, from tools/gemm_bench on MI355X (ViT-B/16 shapes, M = 12608; TFLOP/s with the fused epilogues;
+// profiles/r01f_gemm_microbench.txt, re-checked at the end of the round):
+//                       128x128   160x128   256x256 staggered
+//   N=2304 K= 768 (qkv)    809       784          823
+//   N= 768 K= 768 (proj)   450       534          440        (+ bias + f32 residual)
+//   N=3072 K= 768 (mlp1)   745       744          693        (+ bias + erf-GELU)
+//   N= 768 K=3072 (mlp2)   717       898          785        (+ bias + f32 residual)
+// The tiles differ in FLOP per operand byte (64 / 71 / 128) and in how a grid fills the 256 CUs: 160x128
+// puts 474 tiles on the 512 two-per-CU slots at N = 768 where 128x128 needs two rounds; the 256x256 tile
+// has the K-loop headroom but one workgroup per CU, so its epilogue is not hidden by
+// another workgroup's main loop and its grid quantises worse at this M.  It wins on wide, bf16-output
+// shapes with >= 2 rounds of tiles, and everywhere once a grid has many rounds:
 // On the ViT-L / ViT-H shapes (M = 73856 / 65792 token rows, 4.5+ rounds of 256 x 256 tiles) the
 // staggered 256 x 256 kernel wins every shape by 10-20 % (qkv 1125-1167 vs 929-972 TFLOP/s, mlp2
 // 1122-1131 vs 905-953; hipBLASLt: 1210-1260), so the rule is "enough rounds to amortise the
