@@ -16,7 +16,6 @@ from __future__ import annotations
 import importlib.util
 import json
 import logging
-import math
 import os
 import sys
 import threading
@@ -26,6 +25,7 @@ from urllib.parse import urlencode
 import torch
 
 from .graph import Graph, Pinout
+from .graphjson import chain_graph
 
 logger = logging.getLogger(__name__)
 
@@ -45,7 +45,8 @@ def base_dir() -> str:
 
 
 class NodeKind:
-    """One server-side operator.  Subclasses implement ``io`` and ``compute`` (ref :16-36)."""
+    """One server-side operator (reference :16-36).  Subclasses provide ``io`` and ``compute``; the
+    defaults raise, ``contents`` describes the node by its name and url-encoded parameters."""
 
     def __init__(self, name: str):
         self.name = name
@@ -53,8 +54,11 @@ class NodeKind:
     def get_name(self) -> str:
         return self.name
 
+    def register(self, ctx: "Context") -> None:
+        ctx.register(self)
+
     def contents(self, params: Mapping[str, str]) -> str:
-        return self.name + "?" + urlencode(params)
+        return f"{self.name}?{urlencode(params)}"
 
     def io(self, params: Mapping[str, str]) -> Dict:
         raise Exception(f"TODO: implement Node.io() for {self.name}")
@@ -62,32 +66,27 @@ class NodeKind:
     def compute(self, params: Mapping[str, str], inputs: Pinout) -> Pinout:
         raise Exception(f"TODO: implement Node.compute() for {self.name}")
 
-    def register(self, ctx: "Context") -> None:
-        ctx.register(self)
+
+SINGLE_IO = {"ins": ["o"], "outs": ["o"]}      # every model node: one tensor in on "o", one out on "o" (:94-96)
 
 
-def _is_leaf(sub: torch.nn.Module) -> bool:
-    it = sub.named_modules()
-    next(it)  # the module itself
-    return next(it, None) is None
+def leaf_paths(module: torch.nn.Module) -> List[str]:
+    """Dotted paths of the sub-modules that have no children, in registration order (reference :44-47)."""
+    parents = {path.rpartition(".")[0] for path, _ in module.named_modules() if path}
+    return [path for path, _ in module.named_modules() if path not in parents and (path or not parents)]
 
 
 class Model:
-    """Exposes an ``nn.Module`` as a family of nodes named ``<model>:<dotted path>`` (ref :38-112).
-
-    Every LEAF sub-module becomes a node (ref :44-47).  Plugins override ``list_node_names``,
-    ``compute``, ``contents``, ``io`` and ``generate_graph_json`` the way the reference's
-    ``static/models/vgg16.py`` does.
-    """
+    """An ``nn.Module`` exposed as a family of nodes ``<model>:<dotted path>``, one per leaf sub-module
+    (reference :38-112).  Plugins override ``list_node_names``, ``compute``, ``contents``, ``io`` and
+    ``generate_graph_json`` the way the reference's ``static/models/vgg16.py`` does."""
 
     def __init__(self, model: torch.nn.Module, name: str):
-        self.model = model
-        self.model.eval()
         self.name = name
-        self.node_names: List[str] = [
-            self.prefix() + path for path, sub in self.model.named_modules() if _is_leaf(sub)
-        ]
+        self.model = model.eval()
+        self.node_names: List[str] = [self.prefix() + path for path in leaf_paths(self.model)]
 
+    # -- identity ---------------------------------------------------------------------------------
     def get_name(self) -> str:
         return self.name
 
@@ -97,114 +96,120 @@ class Model:
     def list_node_names(self) -> List[str]:
         return self.node_names
 
-    def generate_graph_json(self) -> Dict:
-        """Client-format graph: a linear chain on channel "o", floor(sqrt(n))-wide grid, 200 px pitch."""
-        names = self.list_node_names()
-        width = int(math.sqrt(len(names)))
-        nodes, edges = [], []
-        for i, name in enumerate(names):
-            nodes.append({
-                "instance": {"kind": "net_node", "endpoint": f"{name}", "params": {}},
-                "pos": {"x": (i % width) * 200, "y": int(i / width) * 200},
-            })
-            if i:
-                edges.append({"in_port": {"node": i - 1, "channel": "o"},
-                              "out_port": {"node": i, "channel": "o"}})
-        return {"nodes": nodes, "edges": edges}
+    def _submodule(self, node_name: str) -> torch.nn.Module:
+        return self.model.get_submodule(node_name.removeprefix(self.prefix()))
 
+    # -- operator interface, per node -----------------------------------------------------------------
     def compute(self, node_name: str, pinin: Pinout) -> Pinout:
+        operand = pinin.get("o")
+        assert operand is not None
         with torch.no_grad():
-            sub = self.model.get_submodule(node_name.removeprefix(self.prefix()))
-            x = pinin.get("o")
-            assert x is not None
-            res = sub(x)
-            assert isinstance(res, torch.Tensor)
-            return Pinout({"o": res})
+            result = self._submodule(node_name)(operand)
+        assert isinstance(result, torch.Tensor)      # tuple-returning modules are not nodes (:85)
+        return Pinout({"o": result})
 
     def contents(self, node_name: str) -> str:
-        sub = self.model.get_submodule(node_name.removeprefix(self.prefix()))
-        return f"<p>{node_name}</p> <p>{sub._get_name()}</p>"
+        return f"<p>{node_name}</p> <p>{self._submodule(node_name)._get_name()}</p>"
 
     def io(self, node_name: str) -> Dict:
-        return {"ins": ["o"], "outs": ["o"]}
+        return dict(SINGLE_IO)
+
+    # -- registration ---------------------------------------------------------------------------------
+    def generate_graph_json(self) -> Dict:
+        return chain_graph(self.list_node_names())
+
+    def _write_graph_file_once(self) -> None:
+        """``static/graphs/<name>.json`` is written on first registration only (reference :98-108); a
+        failure is logged, never fatal."""
+        target = os.path.join(base_dir(), "static/graphs/" + self.name + ".json")
+        if os.path.exists(target):
+            return
+        try:
+            with open(target, "w") as out:
+                out.write(json.dumps(self.generate_graph_json()))
+            logger.info("generated graph %s", target)
+        except Exception as err:
+            logger.error("could not generate graph %s: %s", target, str(err))
 
     def register(self, ctx: "Context") -> None:
-        # ref :98-108: first registration writes static/graphs/<name>.json if it is absent
-        graph_path = os.path.join(base_dir(), "static/graphs/" + self.name + ".json")
-        if not os.path.exists(graph_path):
-            try:
-                with open(graph_path, "w") as f:
-                    f.write(json.dumps(self.generate_graph_json()))
-                logger.info("generated graph %s", graph_path)
-            except Exception as e:
-                logger.error("could not generate graph %s: %s", graph_path, str(e))
+        self._write_graph_file_once()
         for node_name in self.list_node_names():
             ModelNode(self, node_name).register(ctx)
 
 
 class ModelNode(NodeKind):
-    """Adapter: one node of a ``Model`` seen through the ``NodeKind`` interface (ref :114-129)."""
+    """One node of a ``Model`` behind the ``NodeKind`` interface: every call is forwarded to the model
+    with the node's name in place of the request parameters (reference :114-129)."""
 
     def __init__(self, parent: Model, name: str):
         super().__init__(name)
         self.parent = parent
 
-    def compute(self, params: Mapping[str, str], inputs: Pinout) -> Pinout:
-        return self.parent.compute(self.get_name(), inputs)
+    def io(self, params: Mapping[str, str]) -> Dict:
+        return self.parent.io(self.name)
 
     def contents(self, params: Mapping[str, str]) -> str:
-        return self.parent.contents(self.get_name())
+        return self.parent.contents(self.name)
 
-    def io(self, params: Mapping[str, str]) -> Dict:
-        return self.parent.io(self.get_name())
+    def compute(self, params: Mapping[str, str], inputs: Pinout) -> Pinout:
+        return self.parent.compute(self.name, inputs)
 
 
 class Context:
-    """Registry of operators + the per-request executor (ref :132-147)."""
+    """Operator registry and per-request executor (reference :132-147)."""
 
     def __init__(self) -> None:
         self.nodes: Dict[str, NodeKind] = {}
 
     def register(self, node: NodeKind) -> None:
-        logger.info("Registered node: '%s'", node.get_name())
-        self.nodes[node.get_name()] = node
+        key = node.get_name()
+        self.nodes[key] = node
+        logger.info("Registered node: '%s'", key)
 
     def get_node(self, name: str) -> NodeKind:
-        return self.nodes[name]  # unknown endpoint -> KeyError -> HTTP 400, as in the reference
+        return self.nodes[name]      # unknown endpoint: KeyError, which /compute reports as HTTP 400
 
     def compute(self, graph: Graph) -> None:
-        for n in graph.order():
-            n.set_pinout(self.get_node(n.name).compute(n.params, n.get_pinin()))
+        """Evaluates the request graph in ``Graph.order()``: each node reads its inputs off its incoming
+        edges and leaves its outputs on the outgoing ones."""
+        for node in graph.order():
+            operator = self.get_node(node.name)
+            node.set_pinout(operator.compute(node.params, node.get_pinin()))
 
 
-_instance = Context()
-_instance_lock = threading.Lock()
+_singleton = Context()
+_scan_lock = threading.Lock()
 
 
 def context() -> Context:
-    return _instance
+    """The process-wide registry (reference :149-152)."""
+    return _singleton
+
+
+def _load_plugin(path: str):
+    """Imports one plugin file under its bare stem (as the reference does, :160-168: plugins may import each
+    other by that name) and returns the module."""
+    stem = os.path.splitext(os.path.basename(path))[0]
+    spec = importlib.util.spec_from_file_location(stem, path)
+    module = importlib.util.module_from_spec(spec)
+    sys.modules[stem] = module
+    spec.loader.exec_module(module)
+    return module
 
 
 def scan_nodes(dirs: Iterable[str]) -> None:
-    """Import every ``*.py`` under ``<base>/<dir>`` and register what its ``instances()`` returns.
-
-    As in the reference (:154-176) a module is entered into ``sys.modules`` under its bare file
-    stem, and a plugin that fails to import or register is logged and skipped.
-    """
-    with _instance_lock:
+    """Plugin discovery (reference :154-176): every ``*.py`` directly under ``<base>/<dir>`` is imported and
+    whatever its ``instances()`` returns is registered; a plugin that fails to import or to register is
+    logged and skipped."""
+    with _scan_lock:
         for subdir in dirs:
-            full_dir = os.path.join(base_dir(), subdir)
-            for file in os.listdir(full_dir):
-                path = os.path.join(full_dir, file)
-                if not os.path.isfile(path) or not path.endswith(".py"):
+            folder = os.path.join(base_dir(), subdir)
+            for entry in os.listdir(folder):
+                path = os.path.join(folder, entry)
+                if not (path.endswith(".py") and os.path.isfile(path)):
                     continue
-                stem = os.path.splitext(os.path.basename(path))[0]
                 try:
-                    spec = importlib.util.spec_from_file_location(stem, path)
-                    module = importlib.util.module_from_spec(spec)
-                    sys.modules[stem] = module
-                    spec.loader.exec_module(module)
-                    for inst in module.instances():
-                        inst.register(context())
+                    for plugin in _load_plugin(path).instances():
+                        plugin.register(context())
                 except Exception as err:
                     logger.info("Could not register '%s': %s", path, str(err))

@@ -24,12 +24,12 @@ against this package's restatement of it.
 """
 from __future__ import annotations
 
-import math
 import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
 
+from ..graphjson import chain_graph
 from ..vit_config import VARIANTS, VitConfig
 from ..weights import init_weights
 
@@ -103,21 +103,7 @@ def make_vit_model_class(ModelBase, PinoutCls):
             """Chain graph in the client's schema (graph.js:700-758), laid out exactly like
             ``Model.generate_graph_json`` (context.py:55-73) and closed by a ``category`` node the
             way vgg16.py:16-29 does."""
-            names = self.chain_node_names()
-            width = int(math.sqrt(len(names)))
-            nodes, edges = [], []
-            for i, name in enumerate(names):
-                nodes.append({"instance": {"kind": "net_node", "endpoint": f"{name}", "params": {}},
-                              "pos": {"x": (i % width) * 200, "y": int(i / width) * 200}})
-                if i:
-                    edges.append({"in_port": {"node": i - 1, "channel": "o"},
-                                  "out_port": {"node": i, "channel": "o"}})
-            i = len(nodes)
-            w = int(math.sqrt(i))
-            nodes.append({"instance": {"kind": "category", "cats": self.categories},
-                          "pos": {"x": (i % w) * 200, "y": int(i / w) * 200}})
-            edges.append({"in_port": {"node": i - 1, "channel": "o"}, "out_port": {"node": i, "channel": "o"}})
-            return {"nodes": nodes, "edges": edges}
+            return chain_graph(self.chain_node_names(), tail={"kind": "category", "cats": self.categories})
 
         # -- operator interface --------------------------------------------------------------
         def compute(self, node_name: str, pinin):
