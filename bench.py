@@ -255,6 +255,7 @@ def main():
     cpu = None
     if rank == 0:
         from oracle import vit_oracle as vo
+        vo.LN_FOLD = eng.ln_fold        # the rounding-aware oracle mirrors the engine's rounding points
         xs = x[:2].cpu()
         got = logits[:2].cpu().double()
         ref = vo.forward(xs, sd, cfg)["logits"].double()

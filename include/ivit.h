@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define IVIT_ABI_VERSION 4
+#define IVIT_ABI_VERSION 5
 
 #define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
 #define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
@@ -85,6 +85,12 @@ void ivit_destroy(ivit_engine* e);
  * ivit_weights_ready fails and names the first missing tensor if the set is incomplete. */
 int ivit_set_weight(ivit_engine* e, const char* name, const float* host, const int64_t* shape, int ndim);
 int ivit_weights_ready(ivit_engine* e);
+
+/* 1 when the engine folds every LayerNorm of the encoder into the GEMM that consumes it (the default on the
+ * bf16 data path; IVIT_FOLD_LN=0 in the environment at ivit_create keeps the LayerNorm kernel), else 0.
+ * Both forms are bf16 evaluations of the same f32 contract with different rounding points; the parity tests
+ * ask which one the oracle's rounding-aware mode has to mirror. */
+int ivit_ln_fold(const ivit_engine* e);
 
 /* Replaces: Model.compute -> sub(x)  (reference main/context.py:79-88) for a run of nodes.
  * Host-buffer form (interactive path: the request tensors are CPU f32, main/message.py:58):

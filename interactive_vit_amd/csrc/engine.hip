@@ -108,6 +108,9 @@ struct LayerWeights {
     float *b_in = nullptr, *b_out = nullptr, *b1 = nullptr, *b2 = nullptr;
     Matrix w_in, w_out, w1, w2;
     Matrix8 q_in, q_out, q1, q2;                    // fp8 data path only
+    // LayerNorm folded into the GEMM that consumes it: W' = W . diag(gamma) (bf16), s = row sums of W', c = W beta + b
+    Matrix wf_in, wf_1;
+    float *s_in = nullptr, *c_in = nullptr, *s_1 = nullptr, *c_1 = nullptr;
     float s_h1 = 1.f, s_att = 1.f, s_h2 = 1.f, s_u = 1.f;   // static activation scales (calibrated)
 };
 
@@ -117,6 +120,7 @@ struct Ws {
     bf16_t *patches, *h, *qkv, *att, *u, *hc;
     float *x, *clsf;
     unsigned char *h8, *att8, *u8;   // fp8 data path only
+    float2 *ln_part, *ln_stats;      // LayerNorm fold: per-row, per-64-column (sum, M2) pairs; finished (mean, rstd)
 };
 
 struct ivit_engine {
@@ -159,6 +163,9 @@ struct ivit_engine {
     // (launch-bound), and its buffers (ext_in / ext_out / workspaces) never move, so the launch
     // sequence of a (stage range, batch) is captured once and replayed.  IVIT_GRAPHS=0 disables.
     bool graphs_on = true;
+    // LayerNorm fold (bf16 data path; IVIT_FOLD_LN=0 keeps the LayerNorm kernel): see run_layer
+    bool fold_ln = false, fold_ready = false;
+    float2 *ln_part = nullptr, *ln_stats = nullptr;
     int graph_max_batch = 4;
     std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;   // (begin, end, batch, which buffer is the input)
     // chained host calls: the f32 output of the last host call stays in ext_out; a call that presents that
@@ -248,6 +255,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         e->split = sp ? atoi(sp) : 1;
         const char* gr = getenv("IVIT_GRAPHS");
         e->graphs_on = !(gr && atoi(gr) == 0);
+        const char* fl = getenv("IVIT_FOLD_LN");
+        e->fold_ln = !(fl && atoi(fl) == 0) && cfg->precision == IVIT_PRECISION_BF16 && cfg->dim <= 64 * GEMM_LN_SLOTS;
         if (e->split < 1 || e->split > ivit_engine::MAX_SPLIT) e->split = 1;
         for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
             if (hipStreamCreateWithFlags(&e->aux_stream[i], hipStreamNonBlocking) != hipSuccess ||
@@ -268,6 +277,10 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         chk(alloc_matrix(e, &lw.w_out, D, D)); chk(alloc_vec(e, &lw.b_out, D));
         chk(alloc_matrix(e, &lw.w1, Mlp, D)); chk(alloc_vec(e, &lw.b1, Mlp));
         chk(alloc_matrix(e, &lw.w2, D, Mlp)); chk(alloc_vec(e, &lw.b2, D));
+        if (e->fold_ln) {
+            chk(alloc_matrix(e, &lw.wf_in, 3 * D, D)); chk(alloc_vec(e, &lw.s_in, 3 * D)); chk(alloc_vec(e, &lw.c_in, 3 * D));
+            chk(alloc_matrix(e, &lw.wf_1, Mlp, D)); chk(alloc_vec(e, &lw.s_1, Mlp)); chk(alloc_vec(e, &lw.c_1, Mlp));
+        }
         if (rc) break;
     }
     chk(alloc_vec(e, &e->lnf_g, D)); chk(alloc_vec(e, &e->lnf_b, D));
@@ -281,6 +294,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     chk(dev_alloc(e, (void**)&e->att, (size_t)rows_tok * D * 2, true));
     chk(dev_alloc(e, (void**)&e->u, (size_t)rows_tok * Mlp * 2, true));
     chk(dev_alloc(e, (void**)&e->hc, (size_t)(round_up(B, 256) + 256) * D * 2, true));
+    chk(dev_alloc(e, (void**)&e->ln_part, (size_t)rows_tok * GEMM_LN_SLOTS * sizeof(float2), true));
+    chk(dev_alloc(e, (void**)&e->ln_stats, (size_t)rows_tok * sizeof(float2), true));
     if (cfg->precision == IVIT_PRECISION_FP8) {
         e->ld8d = round_up(D, 128); e->ld8m = round_up(Mlp, 128);
         chk(dev_alloc(e, (void**)&e->h8, (size_t)rows_tok * e->ld8d, true));
@@ -404,6 +419,7 @@ extern "C" int ivit_set_weight(ivit_engine* e, const char* name, const float* ho
     e->have[name] = true;
     e->fp8_ready = false;          // quantised copies are rebuilt by the next ivit_fp8_calibrate
     e->weights_complete = false;   // re-evaluated lazily by the next forward / ivit_weights_ready
+    e->fold_ready = false;         // ... which also rebuilds the LayerNorm-folded matrices
     return 0;
 }
 
@@ -412,27 +428,49 @@ static int require_weights(ivit_engine* e) {
     for (const auto& n : all_weight_names(e))
         if (!e->have.count(n)) return fail("weights incomplete: '%s' was never set", n.c_str());
     e->weights_complete = true;
+    if (e->fold_ln && !e->fold_ready) {   // one-time preparation of the folded matrices (device already selected by the caller)
+        hipStream_t st = e->own_stream;
+        for (auto& lw : e->layers) {
+            HIP_TRY(launch_fold_ln_weights(lw.w_in.p, lw.w_in.ld, lw.w_in.rows, lw.w_in.cols, lw.ln1_g, lw.ln1_b, lw.b_in, lw.wf_in.p, lw.s_in, lw.c_in, st));
+            HIP_TRY(launch_fold_ln_weights(lw.w1.p, lw.w1.ld, lw.w1.rows, lw.w1.cols, lw.ln2_g, lw.ln2_b, lw.b1, lw.wf_1.p, lw.s_1, lw.c_1, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        e->fold_ready = true;
+    }
     return 0;
 }
 
 extern "C" int ivit_weights_ready(ivit_engine* e) {
     if (!e) return fail("ivit_weights_ready: null engine");
     std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
     return require_weights(e);
 }
 
+extern "C" int ivit_ln_fold(const ivit_engine* e) { return e && e->fold_ln ? 1 : 0; }
+
 // ------------------------------------------------------------------------------------ forward
+// LayerNorm-fold operands of a GEMM (EPI_BIAS_RESID_STATS: part + xb; EPI_LNFOLD_*: part + s)
+struct LnFold {
+    float2* part = nullptr;
+    const float2* stats = nullptr;
+    bf16_t* xb = nullptr;
+    const float* s = nullptr;
+};
+
 static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, const Matrix& W, int M, const float* bias,
                     int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, const float* rowadd = nullptr,
-                    int ldra = 0, int grp_in = 0, int grp_out = 0, int grp_off = 0) {
+                    int ldra = 0, int grp_in = 0, int grp_out = 0, int grp_off = 0, const LnFold* lf = nullptr) {
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld;
     p.bias = bias; p.epi = epi; p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr;
     p.rowadd = rowadd; p.ldra = ldra; p.grp_in = grp_in; p.grp_out = grp_out; p.grp_off = grp_off;
-    const bool bf_out = (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16);
+    if (lf) { p.ln_part = lf->part; p.ln_stats = lf->stats; p.xb = lf->xb; p.ldxb = e->D; p.ln_s = lf->s; p.ln_eps = e->cfg.ln_eps; p.ln_dim = e->D; }
+    const bool bf_out = (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16 || epi == EPI_LNFOLD_BF16 || epi == EPI_LNFOLD_GELU_BF16);
+    const bool resid_in = (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_RESID_STATS);
     const double flops = 2.0 * M * (double)W.rows * W.cols;
     const double bytes = 2.0 * ((double)M * W.cols + (double)W.rows * W.cols) + (double)M * W.rows * (bf_out ? 2 : 4) +
-                         (epi == EPI_BIAS_RESID_F32 ? 4.0 * M * W.rows : 0.0);
+                         (resid_in ? 4.0 * M * W.rows : 0.0) + (epi == EPI_BIAS_RESID_STATS ? 2.0 * M * W.rows : 0.0);
     ProfScope ps(e, PC_GEMM, st, flops, bytes);
     HIP_TRY(launch_gemm(p, st));
     return 0;
@@ -490,13 +528,45 @@ static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, in
     return 0;
 }
 
-// bf16 layer; amax4 != nullptr (calibration): record max|.| of the four GEMM-input tensors
-static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B, float* amax4 = nullptr) {
+// bf16 layer; amax4 != nullptr (calibration): record max|.| of the four GEMM-input tensors.
+//
+// LayerNorm fold (e->fold_ln, the default on the bf16 data path): no LayerNorm kernel and no LayerNorm output
+// tensor.  The GEMM after a LayerNorm multiplies bf16(x) by W . diag(gamma) and its epilogue applies
+// rstd (acc - mean s) + c (kernels.h: EPI_LNFOLD_*); the row statistics and bf16(x) are left behind by the
+// residual GEMM that produced x (EPI_BIAS_RESID_STATS), or by ivit_row_stats where no GEMM did.
+// `stats_in`: x's statistics / bf16 copy already exist (the previous layer's MLP-down GEMM wrote them);
+// `stats_out`: a layer follows in this call, so this layer's MLP-down GEMM writes them for it.
+static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B, float* amax4 = nullptr, bool stats_in = false,
+                     bool stats_out = false) {
     const int D = e->D, M = B * e->N, Mlp = e->cfg.mlp;
     LayerWeights& lw = e->layers[li];
     if (!amax4 && e->cfg.precision == IVIT_PRECISION_FP8) {
         if (!e->fp8_ready) return fail("fp8 engine is not calibrated: call ivit_fp8_calibrate first");
         return run_layer_fp8(e, w, st, li, B);
+    }
+    if (!amax4 && e->fold_ln) {
+        LnFold fold; fold.part = w.ln_part; fold.stats = w.ln_stats; fold.xb = w.h;
+        auto finalize = [&]() -> int {
+            ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * (D / 64 + 1) * 8.0);
+            HIP_TRY(launch_ln_finalize(w.ln_part, M, D, e->cfg.ln_eps, w.ln_stats, st));
+            return 0;
+        };
+        if (!stats_in) {
+            ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * D * 6.0);
+            HIP_TRY(launch_row_stats(w.x, D, M, D, w.h, D, w.ln_stats, e->cfg.ln_eps, st));
+        }
+        fold.s = lw.s_in;
+        if (run_gemm(e, st, w.h, D, lw.wf_in, M, lw.c_in, EPI_LNFOLD_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, &fold)) return 1;
+        if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
+        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold)) return 1;
+        if (finalize()) return 1;
+        fold.s = lw.s_1;
+        if (run_gemm(e, st, w.h, D, lw.wf_1, M, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &fold)) return 1;
+        if (stats_out) {
+            if (run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold)) return 1;
+            return finalize();
+        }
+        return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D);
     }
     if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.h, D, M, D, amax4 + 0, st));
@@ -571,12 +641,15 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         in_x = true;
         s = ST_LAYER0;
     }
+    bool stats_ready = false;   // LayerNorm fold: the previous layer left x's statistics and bf16 copy behind
     for (; s < end && s < ST_LN; ++s) {
         if (!in_x) {
             HIP_TRY(hipMemcpyAsync(w.x, cur, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
             in_x = true;
         }
-        if (run_layer(e, w, st, s - ST_LAYER0, B)) return 1;
+        const bool more = (s + 1 < end) && (s + 1 < ST_LN);
+        if (run_layer(e, w, st, s - ST_LAYER0, B, nullptr, stats_ready, more)) return 1;
+        stats_ready = more && e->fold_ln && e->cfg.precision == IVIT_PRECISION_BF16;
     }
     if (s >= end) {   // the range ended on an encoder layer: hand the residual stream out
         HIP_TRY(hipMemcpyAsync(out, w.x, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
@@ -638,6 +711,8 @@ static Ws ws_slice(ivit_engine* e, int b0) {
     w.h8 = e->h8 ? e->h8 + rt * e->ld8d : nullptr;
     w.att8 = e->att8 ? e->att8 + rt * e->ld8d : nullptr;
     w.u8 = e->u8 ? e->u8 + rt * e->ld8m : nullptr;
+    w.ln_part = e->ln_part + rt * GEMM_LN_SLOTS;
+    w.ln_stats = e->ln_stats + rt;
     return w;
 }
 

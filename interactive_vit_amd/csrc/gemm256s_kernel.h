@@ -89,7 +89,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
 
 // FP8: A and W are e4m3 BYTE matrices.  A K-tile is 128 bytes of every row either way, so the fp8
 // operands are staged as bf16 matrices of half the row length (lda, ldw % 16 == 0, K % 128 == 0).
-template <int DBG, bool FP8 = false>
+template <int DBG, bool FP8 = false, int EK = 0>
 __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     using T = Tile256P;
     IVIT_STAMP(0);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
 
     if (!late) __builtin_amdgcn_s_barrier();
     IVIT_STAMP(2);
-    gemm_epilogue<T>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq);
+    gemm_epilogue_family<T, EK>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq);
     IVIT_STAMP(3);
     IVIT_VMCNT(0);   // the clamped tail stagings may still be writing LDS
     IVIT_STAMP(4);

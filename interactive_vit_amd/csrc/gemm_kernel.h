@@ -214,6 +214,151 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     else gemm_epilogue_impl<T, false>(p, acc, m_base, n_base, fr, fq);
 }
 
+// ---- LayerNorm-fold epilogues (their own kernel instantiations: the classic kernels stay as they are).
+// EPI_BIAS_RESID_STATS: residual add as EPI_BIAS_RESID_F32; additionally the bf16 copy of the new rows and, per row,
+// the (sum, M2 about the local mean) of this wave's 64 columns -> ln_part[row][n_base / 64].
+template <class T, bool INTERIOR>
+__device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
+    static_assert(T::FN * 16 == 64, "one statistics slot per wave column");
+    const int slot = n_base >> 6;
+    const int ncols = max(0, min(64, p.N - n_base));
+    float4 bias4[T::FN];
+#pragma unroll
+    for (int j = 0; j < T::FN; ++j) {
+        const int n = n_base + j * 16 + fq * 4;
+        if (INTERIOR || n + 3 < p.N) bias4[j] = *reinterpret_cast<const float4*>(p.bias + n);
+        else { float b[4] = {0.f, 0.f, 0.f, 0.f}; for (int r = 0; r < 4; ++r) if (n + r < p.N) b[r] = p.bias[n + r]; bias4[j] = make_float4(b[0], b[1], b[2], b[3]); }
+    }
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i) {
+        const int m = m_base + i * 16 + fr;
+        const bool row_ok = INTERIOR || m < p.M;
+        const int mr = row_ok ? m : p.M - 1;
+        const float* rs = p.resid + (size_t)mr * p.ldr;
+        float4 x[T::FN];
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) {
+            const int n = n_base + j * 16 + fq * 4;
+            if (INTERIOR || n + 3 < p.N) x[j] = *reinterpret_cast<const float4*>(rs + n);
+            else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int r = 0; r < 4; ++r) if (n + r < p.N) t[r] = rs[n + r]; x[j] = make_float4(t[0], t[1], t[2], t[3]); }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) {
+            const int n = n_base + j * 16 + fq * 4;
+            float v[4] = {x[j].x + (acc[i][j][0] + bias4[j].x), x[j].y + (acc[i][j][1] + bias4[j].y),
+                          x[j].z + (acc[i][j][2] + bias4[j].z), x[j].w + (acc[i][j][3] + bias4[j].w)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[i][j][r] = v[r]; if (INTERIOR || n + r < p.N) sum += v[r]; }
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)mr * p.ldo + n;
+            bf16_t* ob = p.xb + (size_t)mr * p.ldxb + n;
+            if (INTERIOR || (row_ok && n + 3 < p.N)) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(ob) = pk;
+            } else if (row_ok) {
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) { o[r] = v[r]; ob[r] = f2bf(v[r]); }
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float lmean = ncols > 0 ? sum / (float)ncols : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) {
+            const int n = n_base + j * 16 + fq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (INTERIOR || n + r < p.N) { const float d = acc[i][j][r] - lmean; m2 = fmaf(d, d, m2); }   // explicit fma: the interior and the edge instantiation must round alike
+        }
+        m2 += __shfl_xor(m2, 16, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        if (fq == 0 && row_ok && ncols > 0) p.ln_part[(size_t)m * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
+    }
+}
+
+// EPI_LNFOLD_*: v = rstd[m] * (acc - mean[m] * s[n]) + c[n]  (c arrives as `bias`), optional GELU, bf16 out.
+// The row statistics arrive finished (ivit_ln_finalize folds the producers' per-slot pairs once per row; doing
+// that here, per wave, cost 6-22 us per GEMM).
+template <class T, bool INTERIOR>
+__device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
+    // finished row statistics (mean, rstd) from ivit_ln_finalize / ivit_row_stats: one 8-byte load per row fragment
+    float mean_i[T::FM], rstd_i[T::FM];
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i) {
+        const int m = min(m_base + i * 16 + fr, p.M - 1);   // rows past M read a valid row's statistics (never stored)
+        const float2 st = p.ln_stats[m];
+        mean_i[i] = st.x;
+        rstd_i[i] = st.y;
+    }
+    float4 c4[T::FN], s4[T::FN];
+#pragma unroll
+    for (int j = 0; j < T::FN; ++j) {
+        const int n = n_base + j * 16 + fq * 4;
+        if (INTERIOR || n + 3 < p.N) { c4[j] = *reinterpret_cast<const float4*>(p.bias + n); s4[j] = *reinterpret_cast<const float4*>(p.ln_s + n); }
+        else {
+            float c[4] = {0.f, 0.f, 0.f, 0.f}, s[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) { c[r] = p.bias[n + r]; s[r] = p.ln_s[n + r]; }
+            c4[j] = make_float4(c[0], c[1], c[2], c[3]); s4[j] = make_float4(s[0], s[1], s[2], s[3]);
+        }
+    }
+    const bool gelu = p.epi == EPI_LNFOLD_GELU_BF16;
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i) {
+        const int m = m_base + i * 16 + fr;
+        if (!INTERIOR && m >= p.M) continue;
+        const float mu = mean_i[i], rs = rstd_i[i];
+        bf16_t* orow_p = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldo;
+        if (INTERIOR && (T::FN % 2 == 0)) {   // 16-byte stores through the fragment-pair lane swap (see gemm_epilogue_impl)
+#pragma unroll
+            for (int j = 0; j < T::FN; j += 2) {
+                float a[4] = {fmaf(rs, fmaf(-mu, s4[j].x, acc[i][j][0]), c4[j].x), fmaf(rs, fmaf(-mu, s4[j].y, acc[i][j][1]), c4[j].y),
+                              fmaf(rs, fmaf(-mu, s4[j].z, acc[i][j][2]), c4[j].z), fmaf(rs, fmaf(-mu, s4[j].w, acc[i][j][3]), c4[j].w)};
+                float b[4] = {fmaf(rs, fmaf(-mu, s4[j + 1].x, acc[i][j + 1][0]), c4[j + 1].x), fmaf(rs, fmaf(-mu, s4[j + 1].y, acc[i][j + 1][1]), c4[j + 1].y),
+                              fmaf(rs, fmaf(-mu, s4[j + 1].z, acc[i][j + 1][2]), c4[j + 1].z), fmaf(rs, fmaf(-mu, s4[j + 1].w, acc[i][j + 1][3]), c4[j + 1].w)};
+                if (gelu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a[r] = gelu_erf(a[r]); b[r] = gelu_erf(b[r]); }
+                }
+                const auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1]), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[2], a[3]), pack_bf16x2(b[2], b[3]), false, false);
+                const int n = n_base + (j + (fq & 1)) * 16 + (fq & ~1) * 4;
+                u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
+                *reinterpret_cast<u32x4*>(orow_p + n) = pk;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) {
+            const int n = n_base + j * 16 + fq * 4;
+            if (n >= p.N) continue;
+            float v[4] = {fmaf(rs, fmaf(-mu, s4[j].x, acc[i][j][0]), c4[j].x), fmaf(rs, fmaf(-mu, s4[j].y, acc[i][j][1]), c4[j].y),
+                          fmaf(rs, fmaf(-mu, s4[j].z, acc[i][j][2]), c4[j].z), fmaf(rs, fmaf(-mu, s4[j].w, acc[i][j][3]), c4[j].w)};
+            if (gelu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            bf16_t* o = orow_p + n;
+            if (n + 3 < p.N) { u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(o) = pk; }
+            else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = f2bf(v[r]);
+        }
+    }
+}
+
+// EK = 0: the classic epilogues; 1: EPI_BIAS_RESID_STATS; 2: EPI_LNFOLD_*
+template <class T, int EK>
+__device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
+    const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
+    if (EK == 0) {
+        gemm_epilogue<T>(p, acc, m_base, n_base, fr, fq);
+    } else if (EK == 1) {
+        if (interior) gemm_epilogue_resid_stats<T, true>(p, acc, m_base, n_base, fr, fq);
+        else gemm_epilogue_resid_stats<T, false>(p, acc, m_base, n_base, fr, fq);
+    } else {
+        if (interior) gemm_epilogue_lnfold<T, true>(p, acc, m_base, n_base, fr, fq);
+        else gemm_epilogue_lnfold<T, false>(p, acc, m_base, n_base, fr, fq);
+    }
+}
+
 // XCD-aware, bijective block -> tile map: blocks that share an XCD (id % 8) get a contiguous run of
 // tiles, n fastest, so neighbours re-use the same A rows out of that XCD's L2.
 __device__ __forceinline__ int xcd_tile(int orig, int nwg) {
@@ -234,7 +379,7 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, 
     tn = panel * group + (within - tm * width);
 }
 
-template <class T, bool FP8 = false>
+template <class T, bool FP8 = false, int EK = 0>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -310,7 +455,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
             }
         }
     }
-    gemm_epilogue<T>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq);
+    gemm_epilogue_family<T, EK>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq);
 }
 
 }  // namespace ivit

@@ -12,6 +12,10 @@ enum GemmEpilogue : int {
     EPI_BIAS_F32 = 3,        // out(f32)   = acc + bias
     EPI_BIAS_ROWADD_F32 = 4, // out(f32)[remap(m)] = (acc + bias) + rowadd[grp_off + m % grp_in]
     EPI_BIAS_GELU_FP8 = 5,   // out(fp8)  = sat_fp8(gelu_erf(acc + bias) * out_scale)
+    // LayerNorm folded into the GEMM that consumes it (kernel family "lnfold", see GemmParams::ln_*):
+    EPI_BIAS_RESID_STATS = 6,   // EPI_BIAS_RESID_F32, plus xb = bf16(out) and the row statistics of out for the NEXT GEMM
+    EPI_LNFOLD_BF16 = 7,        // out(bf16) = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n]        (A = bf16(x), W = bf16(W . gamma))
+    EPI_LNFOLD_GELU_BF16 = 8,   // out(bf16) = gelu_erf(the same)
 };
 
 struct GemmParams {
@@ -26,6 +30,15 @@ struct GemmParams {
     const float* resid; int ldr;  // EPI_BIAS_RESID_F32
     const float* rowadd; int ldra;  // EPI_BIAS_ROWADD_F32: [grp_out, N] table (position embedding)
     int grp_in, grp_out, grp_off;   // row remap m -> (m / grp_in) * grp_out + grp_off + m % grp_in
+    // LayerNorm fold.  Row statistics travel between two GEMMs as per-row, per-64-column (sum, M2) pairs:
+    // EPI_BIAS_RESID_STATS writes ln_part[row][column / 64] and xb; ivit_ln_finalize folds a row's pairs in slot
+    // order (exact two-pass statistics, independent of who wrote them and when) into ln_stats[row] = (mean, rstd),
+    // which EPI_LNFOLD_* reads.
+    float2* ln_part;                // EPI_BIAS_RESID_STATS: [rows][GEMM_LN_SLOTS], written
+    const float2* ln_stats;         // EPI_LNFOLD_*: [rows] finished (mean, rstd), read
+    bf16_t* xb; int ldxb;           // EPI_BIAS_RESID_STATS: bf16 copy of the new residual rows
+    const float* ln_s;              // EPI_LNFOLD_*: s[n] = sum_k W'[n][k]          (bias = c[n])
+    float ln_eps; int ln_dim;       // EPI_LNFOLD_*: LayerNorm epsilon and width (= K of this GEMM)
     int debug;                      // microbenchmark ablations only (0 in the product): 1 = no DMA in the K loop, 2 = no MFMA
     unsigned long long* stamps;     // microbenchmark builds only: per-block s_memrealtime stamps (nullptr in the product)
 };
@@ -75,6 +88,12 @@ hipError_t launch_amax_bf16(const bf16_t* in, int ld, int rows, int cols, float*
 hipError_t launch_quantize_weight_fp8(const bf16_t* w, int ld, int rows, int cols, unsigned char* w8, int ld8, float* rowscale,
                                       hipStream_t s);
 hipError_t launch_scale_vec(const float* in, float a, float* out, int n, hipStream_t s);
+// LayerNorm folded into the GEMM that follows it: weight preparation and row statistics
+constexpr int GEMM_LN_SLOTS = 32;   // 64-column statistics slots per row (dim <= 2048)
+hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, const float* gamma, const float* beta, const float* bias,
+                                  bf16_t* wf, float* s_out, float* c_out, hipStream_t s);
+hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* stats, float eps, hipStream_t s);
+hipError_t launch_ln_finalize(const float2* part, int rows, int dim, float eps, float2* stats, hipStream_t s);
 // strided row gather: out[i,:] = in[i*row_stride, :dim]  (the `cls` node)
 hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, int rows, int dim, hipStream_t s);
 // f32 [rows, cols] -> bf16 [rows, ldo] (columns >= cols zero)

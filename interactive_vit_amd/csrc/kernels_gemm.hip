@@ -23,6 +23,27 @@ __global__ __launch_bounds__(Tile160::THREADS, 2) void ivit_gemm_bf16_160x128x64
     gemm_body<Tile160>(p, smem);
 }
 
+// LayerNorm-fold kernel family: the same bodies with their own epilogues.
+// _rs = residual add + bf16 copy + row statistics for the next GEMM; _lf = LayerNorm applied in the epilogue.
+#define IVIT_LNFOLD_KERNEL(NAME, TILE, EK)                                                    \
+    __global__ __launch_bounds__(TILE::THREADS, 2) void NAME(GemmParams p) {                  \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
+        gemm_body<TILE, false, EK>(p, smem);                                                  \
+    }
+IVIT_LNFOLD_KERNEL(ivit_gemm_bf16_128x128x64_rs, Tile128, 1)
+IVIT_LNFOLD_KERNEL(ivit_gemm_bf16_128x128x64_lf, Tile128, 2)
+IVIT_LNFOLD_KERNEL(ivit_gemm_bf16_160x128x64_rs, Tile160, 1)
+IVIT_LNFOLD_KERNEL(ivit_gemm_bf16_160x128x64_lf, Tile160, 2)
+#undef IVIT_LNFOLD_KERNEL
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag_rs(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256s_body<0, false, 1>(p, smem);
+}
+__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag_lf(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256s_body<0, false, 2>(p, smem);
+}
+
 // fp8 (e4m3) operands: same tiles, K-tile of 128 elements, two fp8 MFMA steps per 16-B fragment
 __global__ __launch_bounds__(Tile128::THREADS, 2) void ivit_gemm_fp8_128x128x128(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,6 +199,18 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
     if (p.K <= 0 || p.K % GEMM_BK != 0) return hipErrorInvalidValue;
     if ((p.lda % 8) || (p.ldw % 8)) return hipErrorInvalidValue;   // 16-B aligned rows for the DMA
     if ((p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
+    const int family = p.epi == EPI_BIAS_RESID_STATS ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
+    if (family) {   // LayerNorm-fold epilogues: their own instantiations of the three product tiles
+        if (p.grp_in != 0) return hipErrorInvalidValue;
+        if (family == 1 && (!p.ln_part || !p.resid || !p.xb || (p.ldxb % 4))) return hipErrorInvalidValue;
+        if (family == 2 && (!p.ln_stats || !p.ln_s)) return hipErrorInvalidValue;
+        switch (variant) {
+            case GEMM_TILE_128: return family == 1 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_rs, p, stream) : launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_lf, p, stream);
+            case GEMM_TILE_160: return family == 1 ? launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_rs, p, stream) : launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_lf, p, stream);
+            case GEMM_TILE_256S: return family == 1 ? launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_rs, p, stream) : launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_lf, p, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (variant) {
         case GEMM_TILE_128: return launch_tile<Tile128>(ivit_gemm_bf16_128x128x64, p, stream);
         case GEMM_TILE_160: return launch_tile<Tile160>(ivit_gemm_bf16_160x128x64, p, stream);

@@ -275,6 +275,127 @@ hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int row
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------- LayerNorm folded into the next GEMM
+// LN(x) W^T + b  =  rstd (x W'^T - mu s) + c     with  W' = W . diag(gamma),  s_n = sum_k W'_nk,  c_n = sum_k beta_k W_nk + b_n.
+// The GEMM multiplies bf16(x) by bf16(W') and its epilogue applies the row statistics (kernels.h: EPI_LNFOLD_*);
+// this kernel prepares W', s and c from the engine's bf16 copy of W.  One wave per weight row.
+__global__ __launch_bounds__(256) void ivit_fold_ln_weights(const bf16_t* __restrict__ w, int ld, int rows, int cols,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ wf, float* __restrict__ s_out,
+                                                            float* __restrict__ c_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* wr = w + (size_t)row * ld;
+    bf16_t* fr = wf + (size_t)row * ld;
+    float s = 0.f, c = 0.f;
+    for (int k = lane; k < ld; k += 64) {
+        float folded = 0.f;
+        if (k < cols) {
+            const float wv = bf2f(wr[k]);
+            const bf16_t q = f2bf(wv * gamma[k]);
+            folded = bf2f(q);
+            c = fmaf(beta[k], wv, c);
+            fr[k] = q;
+        } else {
+            fr[k] = 0;   // K padding stays zero
+        }
+        s += folded;
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if (lane == 0) { s_out[row] = s; c_out[row] = c + bias[row]; }
+}
+
+hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, const float* gamma, const float* beta, const float* bias,
+                                  bf16_t* wf, float* s_out, float* c_out, hipStream_t s) {
+    hipLaunchKernelGGL(ivit_fold_ln_weights, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w, ld, rows, cols, gamma, beta, bias, wf, s_out, c_out);
+    return hipGetLastError();
+}
+
+// Row statistics (mean, rstd) of the residual stream and its bf16 copy, where no GEMM produced the stream (the first
+// layer of a call): what the folded GEMMs read.  One wave per row, two-pass statistics as in ivit_layernorm.
+template <int VPL>
+__global__ __launch_bounds__(256) void ivit_row_stats(const float* __restrict__ x, int ldx, int rows, int dim, bf16_t* __restrict__ xb, int ldxb,
+                                                      float2* __restrict__ stats, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int d4 = dim >> 2;
+    const float* xr = x + (size_t)row * ldx;
+    float4 v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = (c < d4) ? reinterpret_cast<const float4*>(xr)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < d4) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (cc * cc + d * d);
+            u32x2 pk = {pack_bf16x2(v[i].x, v[i].y), pack_bf16x2(v[i].z, v[i].w)};
+            reinterpret_cast<u32x2*>(xb + (size_t)row * ldxb)[c] = pk;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)dim + eps);
+    if (lane == 0) stats[row] = make_float2(mean, rstd);
+}
+
+hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* stats, float eps, hipStream_t s) {
+    if (dim % 4 || dim > 64 * 4 * 8) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    const dim3 grid(ceil_div(rows, 4)), block(256);
+    const int vpl = ceil_div(dim / 4, 64);
+#define IVIT_RS(V) hipLaunchKernelGGL(ivit_row_stats<V>, grid, block, 0, s, x, ldx, rows, dim, xb, ldxb, stats, eps)
+    if (vpl <= 1) IVIT_RS(1);
+    else if (vpl <= 2) IVIT_RS(2);
+    else if (vpl <= 3) IVIT_RS(3);
+    else if (vpl <= 4) IVIT_RS(4);
+    else if (vpl <= 5) IVIT_RS(5);
+    else IVIT_RS(8);
+#undef IVIT_RS
+    return hipGetLastError();
+}
+
+// Folds the per-64-column (sum, M2) pairs a residual GEMM left per row (EPI_BIAS_RESID_STATS) into (mean, rstd):
+// Chan's combination in slot order - exact two-pass statistics, the same bits whatever tile shape wrote the pairs.
+// One thread per row.
+__global__ __launch_bounds__(256) void ivit_ln_finalize(const float2* __restrict__ part, int rows, int dim, float eps, float2* __restrict__ stats) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int nslots = (dim + 63) >> 6;
+    const float4* pr = reinterpret_cast<const float4*>(part + (size_t)row * GEMM_LN_SLOTS);
+    float4 raw[GEMM_LN_SLOTS / 2];
+#pragma unroll
+    for (int l = 0; l < GEMM_LN_SLOTS / 2; ++l) raw[l] = (2 * l < nslots) ? pr[l] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float mean = 0.f, m2 = 0.f, na = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < GEMM_LN_SLOTS; ++s2) {
+        const int nk = max(0, min(64, dim - s2 * 64));
+        if (s2 < nslots && nk > 0) {
+            const float sm = (s2 & 1) ? raw[s2 >> 1].z : raw[s2 >> 1].x, mm = (s2 & 1) ? raw[s2 >> 1].w : raw[s2 >> 1].y;
+            const float nb = (float)nk, nn = na + nb, d = sm / nb - mean;
+            mean += d * (nb / nn);
+            m2 += mm + d * d * (na * nb / nn);
+            na = nn;
+        }
+    }
+    stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)dim + eps));
+}
+
+hipError_t launch_ln_finalize(const float2* part, int rows, int dim, float eps, float2* stats, hipStream_t s) {
+    if (dim <= 0 || dim > 64 * GEMM_LN_SLOTS) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ivit_ln_finalize, dim3(ceil_div(rows, 256)), dim3(256), 0, s, part, rows, dim, eps, stats);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------- gather / convert
 __global__ void ivit_gather_rows(const float* __restrict__ in, int64_t row_stride, float* __restrict__ out, int rows, int dim) {
     const int d4 = dim >> 2;

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libivit.so")
 # every symbol include/ivit.h declares (tests check the built library exports each one)
 ABI_SYMBOLS = (
     "ivit_abi_version", "ivit_build_info", "ivit_last_error", "ivit_stage_count", "ivit_stage_shape",
-    "ivit_unfold_offset", "ivit_create", "ivit_destroy", "ivit_set_weight", "ivit_weights_ready",
+    "ivit_unfold_offset", "ivit_create", "ivit_destroy", "ivit_set_weight", "ivit_weights_ready", "ivit_ln_fold",
     "ivit_forward_host", "ivit_forward_host_chained", "ivit_forward_device", "ivit_preprocess", "ivit_preprocess_host", "ivit_attention_map", "ivit_attention_map_host",
     "ivit_fp8_calibrate", "ivit_fp8_scales", "ivit_debug_unfold", "ivit_profile_enable",
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
@@ -36,7 +36,7 @@ class IvitConfigC(ctypes.Structure):
                 ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PRECISIONS = {"bf16": 0, "fp8": 1}
 
 
@@ -73,6 +73,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_destroy.restype = None
         lib.ivit_set_weight.argtypes = [c_p, ctypes.c_char_p, c_p, ctypes.POINTER(c_i64), c_i]
         lib.ivit_weights_ready.argtypes = [c_p]
+        lib.ivit_ln_fold.argtypes = [c_p]
+        lib.ivit_ln_fold.restype = c_i
         lib.ivit_forward_host.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64]
         lib.ivit_forward_host_chained.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         lib.ivit_preprocess_host.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_i64, ctypes.POINTER(ctypes.c_uint64)]
@@ -133,6 +135,7 @@ class Engine:
         if self.lib.ivit_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libivit.so has ABI {self.lib.ivit_abi_version()}, this binding needs {ABI_VERSION}: rebuild")
         self.cfg = cfg
+        self.ln_fold = False      # set after creation: does the engine fold LayerNorm into the next GEMM (ivit_ln_fold)
         self._pin = os.environ.get("IVIT_PINNED_OUTPUTS", "1") != "0"
         self._last_out = None     # (weakref to the last host-path output, its version counter, its residency token)
         self.device = int(device)
@@ -142,6 +145,7 @@ class Engine:
         self._h = ctypes.c_void_p()
         c = _config_c(cfg, self.device, self.max_batch, precision)
         self._check(self.lib.ivit_create(ctypes.byref(c), ctypes.byref(self._h)))
+        self.ln_fold = bool(self.lib.ivit_ln_fold(self._h))
         try:
             for name, t in state_dict.items():
                 self.set_weight(name, t)

@@ -196,8 +196,48 @@ def attention_map(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> to
     return attention(h, sd, i, cfg, return_probs=True, emulate=emulate)[1]
 
 
+# Which rounding points the rounding-aware mode (emulate=True) mirrors inside an encoder layer.  The engine's
+# default on the bf16 data path folds each LayerNorm into the GEMM that consumes it (include/ivit.h:
+# ivit_ln_fold): the GEMM multiplies bf16(x) by bf16(W . diag(gamma)) and applies
+# rstd * (acc - mean * s) + c in its epilogue, s = row sums of the rounded W', c = W beta + b.  Same f32
+# contract, different bf16 rounding points (their distance from the f32 forward is the same: 1.4e-3 per layer on
+# ViT-B/16).  Tests / bench / smoke set this from Engine.ln_fold; the plain (emulate=False) forward never looks at it.
+LN_FOLD = False
+
+
+def folded_linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    """LayerNorm(x) @ w.T + b as the engine's folded GEMM evaluates it (x: [..., D] in the compute dtype)."""
+    dt = x.dtype
+    wb = w.to(torch.float32).to(torch.bfloat16).to(dt)                       # the engine's bf16 copy of W
+    wf = (wb * gamma.to(dt)[None, :]).to(torch.float32).to(torch.bfloat16).to(dt)   # W . diag(gamma), rounded again
+    s = wf.sum(dim=1)
+    c = wb @ beta.to(dt) + b.to(dt)
+    mu = x.mean(dim=-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((x - mu) ** 2).mean(dim=-1, keepdim=True) + eps)
+    xb = x.to(torch.float32).to(torch.bfloat16).to(dt)
+    return rstd * (xb @ wf.t() - mu * s) + c
+
+
+def _encoder_layer_fold(x: torch.Tensor, sd, i: int, cfg) -> torch.Tensor:
+    dt = x.dtype
+    pre = layer_prefix(i)
+    b, n, d = x.shape
+    hd = cfg.head_dim
+    qkv = rnd(folded_linear(x, sd[pre + "self_attention.in_proj_weight"], sd[pre + "self_attention.in_proj_bias"],
+                            sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], cfg.ln_eps), True)
+    q, k, v = [t.reshape(b, n, cfg.heads, hd).transpose(1, 2) for t in qkv.split(d, dim=-1)]
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+    a = rnd(((rnd(e, True) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(b, n, d), True)
+    x = x + a @ _w(sd, pre + "self_attention.out_proj.weight", dt, True).t() + _w(sd, pre + "self_attention.out_proj.bias", dt)
+    u = rnd(gelu_erf(folded_linear(x, sd[pre + "mlp.0.weight"], sd[pre + "mlp.0.bias"], sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"], cfg.ln_eps)), True)
+    return x + u @ _w(sd, pre + "mlp.3.weight", dt, True).t() + _w(sd, pre + "mlp.3.bias", dt)
+
+
 def encoder_layer(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> torch.Tensor:
     """Residual-inclusive block i: [B,N,D] -> [B,N,D]."""
+    if emulate and LN_FOLD:
+        return _encoder_layer_fold(x, sd, i, cfg)
     dt = x.dtype
     pre = layer_prefix(i)
     h = rnd(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), emulate)

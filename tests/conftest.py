@@ -17,3 +17,14 @@ def built_lib():
     """libivit.so, built in-tree if the prebuilt one is stale or absent (hipcc cross-compiles)."""
     from interactive_vit_amd import build
     return build.build()
+
+
+@pytest.fixture(autouse=True)
+def oracle_mirrors_engine_rounding_points():
+    """The oracle's rounding-aware mode mirrors the rounding points of the engine build under test: LayerNorm
+    folded into the next GEMM (the bf16 default, IVIT_FOLD_LN unset or 1) or a LayerNorm kernel (IVIT_FOLD_LN=0).
+    Engine.ln_fold reports what an engine actually does; the GPU tests assert that it agrees with this."""
+    from oracle import vit_oracle
+    vit_oracle.LN_FOLD = os.environ.get("IVIT_FOLD_LN", "1") != "0"
+    yield
+    vit_oracle.LN_FOLD = False

@@ -56,6 +56,13 @@ def small():
     eng.close()
 
 
+def test_oracle_mirrors_the_engine_rounding_points(small):
+    """conftest sets the oracle's LayerNorm-fold switch from IVIT_FOLD_LN; the engine reports what it does."""
+    from oracle import vit_oracle
+    cfg, sd, eng = small
+    assert eng.ln_fold == vit_oracle.LN_FOLD
+
+
 def test_library_is_the_hip_build(built_lib):
     from interactive_vit_amd import engine
     lib = engine.load_library()

@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
         {"qkv   ", Mfull, 2304, 768, EPI_BIAS_BF16}, {"proj  ", Mfull, 768, 768, EPI_BIAS_RESID_F32},
         {"mlp1  ", Mfull, 3072, 768, EPI_BIAS_GELU_BF16}, {"mlp2  ", Mfull, 768, 3072, EPI_BIAS_RESID_F32},
         {"patch ", 64 * 196, 768, 768, EPI_BIAS_F32}, {"mlp1ng", Mfull, 3072, 768, EPI_BIAS_BF16},
+        {"projRS", Mfull, 768, 768, EPI_BIAS_RESID_STATS}, {"mlp2RS", Mfull, 768, 3072, EPI_BIAS_RESID_STATS},
     };
     const char* set = getenv("IVIT_SHAPES");   // "vith": the ViT-H/14 layer shapes (dim 1280, mlp 5120)
     if (set && !strcmp(set, "vith"))
@@ -69,6 +70,10 @@ int main(int argc, char** argv) {
     const int max_blocks = 4096;
     CK(hipMalloc(&dstamps, (size_t)max_blocks * 16 * 8));
 
+    // LayerNorm-fold epilogues: statistics table and bf16 copy
+    float2* dpart; bf16_t* dxb;
+    CK(hipMalloc(&dpart, (size_t)maxM * GEMM_LN_SLOTS * 8)); CK(hipMalloc(&dxb, (size_t)maxM * maxN * 2));
+
     int shape_idx = -1;
     for (const Shape& s : shapes) {
         ++shape_idx;
@@ -76,6 +81,7 @@ int main(int argc, char** argv) {
         GemmParams p{};
         p.A = dA; p.lda = s.K; p.W = dW; p.ldw = s.K; p.M = s.M; p.N = s.N; p.K = s.K; p.bias = db; p.epi = s.epi;
         p.out = dout; p.ldo = s.N; p.resid = dres; p.ldr = s.N; p.debug = debug;
+        p.ln_part = dpart; p.xb = dxb; p.ldxb = s.N;
         // correctness on sampled rows (epilogue F32 so the values are comparable)
         std::vector<int> rows(NR);
         for (int i = 0; i < NR; ++i) rows[i] = (int)((long long)i * (s.M - 1) / (NR - 1));
@@ -99,9 +105,31 @@ int main(int argc, char** argv) {
             }
             printf("   %-28s check: max err %.3e (max ref %.3f) %s\n", gemm_variant_name(v), maxerr, maxref, maxerr <= 1e-3 * maxref ? "OK" : "MISMATCH");
         }
+        if (s.epi == EPI_BIAS_RESID_STATS) {   // the statistics and the bf16 copy must not depend on the tile shape: bitwise
+            std::vector<unsigned long long> base, cur((size_t)s.M * GEMM_LN_SLOTS);
+            std::vector<unsigned short> xbase, xcur((size_t)s.M * s.N);
+            for (int v : {GEMM_TILE_160, GEMM_TILE_128, GEMM_TILE_256S}) {
+                CK(hipMemset(dpart, 0, (size_t)s.M * GEMM_LN_SLOTS * 8));
+                CK(launch_gemm_variant(p, v, 0));
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(cur.data(), dpart, cur.size() * 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(xcur.data(), dxb, xcur.size() * 2, hipMemcpyDeviceToHost));
+                if (base.empty()) { base = cur; xbase = xcur; continue; }
+                size_t bad = 0, xbad = 0, first = (size_t)-1;
+                for (size_t i = 0; i < cur.size(); ++i) if (cur[i] != base[i]) { if (!bad) first = i; ++bad; }
+                for (size_t i = 0; i < xcur.size(); ++i) if (xcur[i] != xbase[i]) ++xbad;
+                printf("   %-28s row statistics vs 160x128: %zu of %zu pairs differ%s; bf16 copy: %zu differ\n", gemm_variant_name(v), bad, cur.size(),
+                       bad ? "" : " (bit-identical)", xbad);
+                if (bad) {
+                    float a[2], b[2]; memcpy(a, &base[first], 8); memcpy(b, &cur[first], 8);
+                    printf("      first: row %zu slot %zu: (%.9g, %.9g) vs (%.9g, %.9g)\n", first / GEMM_LN_SLOTS, first % GEMM_LN_SLOTS, a[0], a[1], b[0], b[1]);
+                }
+            }
+        }
         for (int round = 0; round < rounds; ++round)
             for (int v = 0; v < GEMM_VARIANTS; ++v) {
                 if (!((vmask >> v) & 1)) continue;
+                if (s.epi >= EPI_BIAS_RESID_STATS && v != GEMM_TILE_128 && v != GEMM_TILE_160 && v != GEMM_TILE_256S) continue;
                 const int iters = rounds >= 7 ? 10 : 2;
                 CK(launch_gemm_variant(p, v, 0));
                 CK(hipEventRecord(e0, 0));
@@ -159,7 +187,7 @@ int main(int argc, char** argv) {
             printf("      blocks starting > 5 us after the first: %d\n", late_blocks);
         }
         for (int v = 0; v < GEMM_VARIANTS; ++v) {
-            if (!((vmask >> v) & 1)) continue;
+            if (!((vmask >> v) & 1) || times[v].empty()) continue;
             std::sort(times[v].begin(), times[v].end());
             const double med = times[v][times[v].size() / 2], mn = times[v][0];
             best[v] = med;
