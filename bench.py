@@ -255,7 +255,7 @@ def main():
     cpu = None
     if rank == 0:
         from oracle import vit_oracle as vo
-        vo.LN_FOLD = eng.ln_fold        # the rounding-aware oracle mirrors the engine's rounding points
+        vo.LN_FOLD = eng.ln_fold_for(B)  # the rounding-aware oracle mirrors the rounding points of THIS batch size
         xs = x[:2].cpu()
         got = logits[:2].cpu().double()
         ref = vo.forward(xs, sd, cfg)["logits"].double()

@@ -86,11 +86,12 @@ void ivit_destroy(ivit_engine* e);
 int ivit_set_weight(ivit_engine* e, const char* name, const float* host, const int64_t* shape, int ndim);
 int ivit_weights_ready(ivit_engine* e);
 
-/* 1 when the engine folds every LayerNorm of the encoder into the GEMM that consumes it (the default on the
- * bf16 data path; IVIT_FOLD_LN=0 in the environment at ivit_create keeps the LayerNorm kernel), else 0.
- * Both forms are bf16 evaluations of the same f32 contract with different rounding points; the parity tests
+/* 1 when a forward of `batch` images folds every LayerNorm of the encoder into the GEMM that consumes it, else 0.
+ * The fold is the default on the bf16 data path (IVIT_FOLD_LN=0 in the environment at ivit_create disables it) for
+ * calls whose residual GEMMs run two workgroups per CU; calls large enough for the 256x256 tile keep the LayerNorm
+ * kernel.  Both forms are bf16 evaluations of the same f32 contract with different rounding points; the parity tests
  * ask which one the oracle's rounding-aware mode has to mirror. */
-int ivit_ln_fold(const ivit_engine* e);
+int ivit_ln_fold(const ivit_engine* e, int batch);
 
 /* Replaces: Model.compute -> sub(x)  (reference main/context.py:79-88) for a run of nodes.
  * Host-buffer form (interactive path: the request tensors are CPU f32, main/message.py:58):

@@ -447,7 +447,11 @@ extern "C" int ivit_weights_ready(ivit_engine* e) {
     return require_weights(e);
 }
 
-extern "C" int ivit_ln_fold(const ivit_engine* e) { return e && e->fold_ln ? 1 : 0; }
+static bool fold_for_rows(const ivit_engine* e, int M);
+extern "C" int ivit_ln_fold(const ivit_engine* e, int batch) {
+    if (!e || batch <= 0) return 0;
+    return fold_for_rows(e, batch * e->N) ? 1 : 0;
+}
 
 // ------------------------------------------------------------------------------------ forward
 // LayerNorm-fold operands of a GEMM (EPI_BIAS_RESID_STATS: part + xb; EPI_LNFOLD_*: part + s)
@@ -528,6 +532,14 @@ static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, in
     return 0;
 }
 
+// The LayerNorm fold pays where the residual GEMMs run two workgroups per CU (their longer epilogue hides behind
+// the other workgroup's main loop: ViT-B/16 +3.5 %); where they take the 256x256 tile (ViT-L / ViT-H batches, one
+// workgroup per CU) the exposed epilogue costs more than the LayerNorm kernels it saves (-1...-2 %), so those calls
+// keep the LayerNorm kernel.  Same weights, decided per call from the token-row count.
+static bool fold_for_rows(const ivit_engine* e, int M) {
+    return e->fold_ln && !gemm_prefers_256(M, e->D, e->D);
+}
+
 // bf16 layer; amax4 != nullptr (calibration): record max|.| of the four GEMM-input tensors.
 //
 // LayerNorm fold (e->fold_ln, the default on the bf16 data path): no LayerNorm kernel and no LayerNorm output
@@ -544,7 +556,7 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         if (!e->fp8_ready) return fail("fp8 engine is not calibrated: call ivit_fp8_calibrate first");
         return run_layer_fp8(e, w, st, li, B);
     }
-    if (!amax4 && e->fold_ln) {
+    if (!amax4 && fold_for_rows(e, M)) {
         LnFold fold; fold.part = w.ln_part; fold.stats = w.ln_stats; fold.xb = w.h;
         auto finalize = [&]() -> int {
             ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * (D / 64 + 1) * 8.0);
@@ -649,7 +661,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         }
         const bool more = (s + 1 < end) && (s + 1 < ST_LN);
         if (run_layer(e, w, st, s - ST_LAYER0, B, nullptr, stats_ready, more)) return 1;
-        stats_ready = more && e->fold_ln && e->cfg.precision == IVIT_PRECISION_BF16;
+        stats_ready = more && fold_for_rows(e, B * N);
     }
     if (s >= end) {   // the range ended on an encoder layer: hand the residual stream out
         HIP_TRY(hipMemcpyAsync(out, w.x, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));

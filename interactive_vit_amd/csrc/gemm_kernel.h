@@ -344,7 +344,8 @@ __device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 
     }
 }
 
-// EK = 0: the classic epilogues; 1: EPI_BIAS_RESID_STATS; 2: EPI_LNFOLD_*
+// EK = 0: the classic epilogues (kind chosen at run time); 1: EPI_BIAS_RESID_STATS; 2: EPI_LNFOLD_*.
+// (One kernel per classic kind was tried too: no gain at the ViT-B shapes, 5-15 % slower at the ViT-H shapes.)
 template <class T, int EK>
 __device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
     const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);

@@ -51,6 +51,7 @@ hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);                       // picks the tile
 hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream);
 int gemm_pick_variant(int M, int N, int K);
+bool gemm_prefers_256(int M, int N, int K);   // the one-workgroup-per-CU 256x256 tile is picked (many rounds of tiles)
 const char* gemm_variant_name(int v);
 
 // ---------------------------------------------------------------- attention (kernels_attn.hip)

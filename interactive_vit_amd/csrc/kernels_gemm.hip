@@ -7,6 +7,8 @@
 #include "study/gemm160x256w4_kernel.h"
 #endif
 #include <cmath>
+#include <mutex>
+#include <set>
 
 namespace ivit {
 
@@ -116,11 +118,17 @@ const char* gemm_variant_name(int v) {
 
 template <class T, class K>
 static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream) {
-    static bool attr_set = false;   // one process drives one GPU
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    // once per kernel (all kernels share one function-pointer type, so the bookkeeping is by address; one process
+    // drives one GPU)
+    static std::mutex mu;
+    static std::set<const void*> configured;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!configured.count(reinterpret_cast<const void*>(kernel))) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            configured.insert(reinterpret_cast<const void*>(kernel));
+        }
     }
     const int tiles = ceil_div(p.M, T::BM) * ceil_div(p.N, T::BN);
     hipLaunchKernelGGL(kernel, dim3(tiles), dim3(T::THREADS), T::LDS_BYTES, stream, p);
@@ -143,7 +151,7 @@ static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream)
 // staggered 256 x 256 kernel wins every shape by 10-20 % (qkv 1125-1167 vs 929-972 TFLOP/s, mlp2
 // 1122-1131 vs 905-953; hipBLASLt: 1210-1260), so the rule is "enough rounds to amortise the
 // exposed epilogue and the ragged last round".
-static bool gemm_prefers_256(int M, int N, int K) {
+bool gemm_prefers_256(int M, int N, int K) {
     if (N >= 2048 && N <= 2560 && K <= 1024 && M >= 4096) return true;   // ViT-B QKV-like (1.8 rounds, bf16 out)
     const double rounds = (double)ceil_div(M, 256) * ceil_div(N, 256) / 256.0;
     return rounds >= 3.0;

@@ -73,7 +73,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_destroy.restype = None
         lib.ivit_set_weight.argtypes = [c_p, ctypes.c_char_p, c_p, ctypes.POINTER(c_i64), c_i]
         lib.ivit_weights_ready.argtypes = [c_p]
-        lib.ivit_ln_fold.argtypes = [c_p]
+        lib.ivit_ln_fold.argtypes = [c_p, c_i]
         lib.ivit_ln_fold.restype = c_i
         lib.ivit_forward_host.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64]
         lib.ivit_forward_host_chained.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
@@ -145,7 +145,7 @@ class Engine:
         self._h = ctypes.c_void_p()
         c = _config_c(cfg, self.device, self.max_batch, precision)
         self._check(self.lib.ivit_create(ctypes.byref(c), ctypes.byref(self._h)))
-        self.ln_fold = bool(self.lib.ivit_ln_fold(self._h))
+        self.ln_fold = bool(self.lib.ivit_ln_fold(self._h, 1))      # small batches; ln_fold_for(batch) for a given size
         try:
             for name, t in state_dict.items():
                 self.set_weight(name, t)
@@ -281,6 +281,11 @@ class Engine:
         self._check(self.lib.ivit_preprocess(self._h, batch, ctypes.c_void_p(xin.data_ptr()), h, w,
                                              ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
         return out
+
+    def ln_fold_for(self, batch: int) -> bool:
+        """Does a forward of `batch` images fold the encoder's LayerNorms into the following GEMMs
+        (include/ivit.h: ivit_ln_fold)?  What the rounding-aware oracle has to mirror for that call."""
+        return bool(self.lib.ivit_ln_fold(self._h, int(batch)))
 
     def run_node(self, suffix: str, x: torch.Tensor) -> torch.Tensor:
         if suffix == "preprocess":
