@@ -557,12 +557,8 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         return run_layer_fp8(e, w, st, li, B);
     }
     if (!amax4 && fold_for_rows(e, M)) {
-        LnFold fold; fold.part = w.ln_part; fold.stats = w.ln_stats; fold.xb = w.h;
-        auto finalize = [&]() -> int {
-            ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * (D / 64 + 1) * 8.0);
-            HIP_TRY(launch_ln_finalize(w.ln_part, M, D, e->cfg.ln_eps, w.ln_stats, st));
-            return 0;
-        };
+        LnFold fold; fold.part = w.ln_part; fold.xb = w.h;
+        fold.stats = stats_in ? nullptr : w.ln_stats;      // finished statistics only where ivit_row_stats made them
         if (!stats_in) {
             ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * D * 6.0);
             HIP_TRY(launch_row_stats(w.x, D, M, D, w.h, D, w.ln_stats, e->cfg.ln_eps, st));
@@ -571,13 +567,10 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         if (run_gemm(e, st, w.h, D, lw.wf_in, M, lw.c_in, EPI_LNFOLD_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, &fold)) return 1;
         if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
         if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold)) return 1;
-        if (finalize()) return 1;
         fold.s = lw.s_1;
+        fold.stats = nullptr;                               // the out-projection's epilogue left the pairs: fold them in the consumer
         if (run_gemm(e, st, w.h, D, lw.wf_1, M, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &fold)) return 1;
-        if (stats_out) {
-            if (run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold)) return 1;
-            return finalize();
-        }
+        if (stats_out) return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold);
         return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D);
     }
     if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;

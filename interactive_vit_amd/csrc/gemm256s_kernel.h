@@ -123,6 +123,9 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float2* tile_stats = reinterpret_cast<float2*>(smem + T::LDS_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
+    if (EK == 2) ln_tile_stats<T>(p, m0, tile_stats);
+
     const int nt = p.K / (FP8 ? 2 * GEMM_BK : GEMM_BK);
     const int last_kt = nt - 1;
     // ---- prologue: DMA queue in steady-state order: tile 0 = A0 B0 B1 A1, tile 1 = A0 B0
@@ -145,7 +148,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
 
     if (!late) __builtin_amdgcn_s_barrier();
     IVIT_STAMP(2);
-    gemm_epilogue_family<T, EK>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq);
+    gemm_epilogue_family<T, EK>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq, tile_stats + wr * 128);
     IVIT_STAMP(3);
     IVIT_VMCNT(0);   // the clamped tail stagings may still be writing LDS
     IVIT_STAMP(4);

@@ -277,16 +277,16 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
 }
 
 // EPI_LNFOLD_*: v = rstd[m] * (acc - mean[m] * s[n]) + c[n]  (c arrives as `bias`), optional GELU, bf16 out.
-// The row statistics arrive finished (ivit_ln_finalize folds the producers' per-slot pairs once per row; doing
-// that here, per wave, cost 6-22 us per GEMM).
+// The row statistics are read from LDS, where ln_tile_stats put them while the first operand tiles were in flight
+// (folding the producers' pairs here, per wave, cost 6-22 us per GEMM; a separate finalize kernel 5 us per LayerNorm).
 template <class T, bool INTERIOR>
-__device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
-    // finished row statistics (mean, rstd) from ivit_ln_finalize / ivit_row_stats: one 8-byte load per row fragment
+__device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
+                                                     const float2* tile_stats) {
+    // finished row statistics (mean, rstd) of the tile's rows, left in LDS by ln_tile_stats at the start of the kernel
     float mean_i[T::FM], rstd_i[T::FM];
 #pragma unroll
     for (int i = 0; i < T::FM; ++i) {
-        const int m = min(m_base + i * 16 + fr, p.M - 1);   // rows past M read a valid row's statistics (never stored)
-        const float2 st = p.ln_stats[m];
+        const float2 st = tile_stats[i * 16 + fr];
         mean_i[i] = st.x;
         rstd_i[i] = st.y;
     }
@@ -344,10 +344,49 @@ __device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 
     }
 }
 
+// (mean, rstd) of the BM rows of this workgroup's tile -> LDS, one thread per row, at the very start of the kernel
+// (the loads overlap the first operand DMA).  Source: finished statistics (ln_stats: ivit_row_stats wrote them) or the
+// per-64-column (sum, M2) pairs a residual GEMM left (ln_part), folded in slot order with Chan's formula - exact
+// two-pass statistics, the same bits whatever tile shape wrote the pairs and whichever column tile folds them.
+template <class T>
+__device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float2* tile_stats) {
+    for (int r = threadIdx.x; r < T::BM; r += T::THREADS) {
+        const int m = min(m0 + r, p.M - 1);     // rows past M: a valid row's statistics (their outputs are never stored)
+        float2 st;
+        if (p.ln_stats) {
+            st = p.ln_stats[m];
+        } else {
+            const int nslots = (p.ln_dim + 63) >> 6;
+            const float4* pr = reinterpret_cast<const float4*>(p.ln_part + (size_t)m * GEMM_LN_SLOTS);
+            float mean = 0.f, m2 = 0.f, na = 0.f;
+            for (int s0 = 0; s0 < nslots; s0 += 12) {
+                float4 raw[6];
+#pragma unroll
+                for (int l = 0; l < 6; ++l) raw[l] = pr[min((s0 >> 1) + l, GEMM_LN_SLOTS / 2 - 1)];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    const int s2 = s0 + q;
+                    const int nk = max(0, min(64, p.ln_dim - s2 * 64));
+                    if (s2 < nslots && nk > 0) {
+                        const float sm = (q & 1) ? raw[q >> 1].z : raw[q >> 1].x, mm = (q & 1) ? raw[q >> 1].w : raw[q >> 1].y;
+                        const float nb = (float)nk, nn = na + nb, d = sm / nb - mean;
+                        mean = fmaf(d, nb / nn, mean);
+                        m2 = fmaf(d * d, na * nb / nn, m2 + mm);
+                        na = nn;
+                    }
+                }
+            }
+            st = make_float2(mean, 1.0f / sqrtf(m2 / (float)p.ln_dim + p.ln_eps));
+        }
+        tile_stats[r] = st;
+    }
+}
+
 // EK = 0: the classic epilogues (kind chosen at run time); 1: EPI_BIAS_RESID_STATS; 2: EPI_LNFOLD_*.
 // (One kernel per classic kind was tried too: no gain at the ViT-B shapes, 5-15 % slower at the ViT-H shapes.)
 template <class T, int EK>
-__device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
+__device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
+                                                     const float2* tile_stats = nullptr) {
     const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
     if (EK == 0) {
         gemm_epilogue<T>(p, acc, m_base, n_base, fr, fq);
@@ -355,8 +394,8 @@ __device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 
         if (interior) gemm_epilogue_resid_stats<T, true>(p, acc, m_base, n_base, fr, fq);
         else gemm_epilogue_resid_stats<T, false>(p, acc, m_base, n_base, fr, fq);
     } else {
-        if (interior) gemm_epilogue_lnfold<T, true>(p, acc, m_base, n_base, fr, fq);
-        else gemm_epilogue_lnfold<T, false>(p, acc, m_base, n_base, fr, fq);
+        if (interior) gemm_epilogue_lnfold<T, true>(p, acc, m_base, n_base, fr, fq, tile_stats);
+        else gemm_epilogue_lnfold<T, false>(p, acc, m_base, n_base, fr, fq, tile_stats);
     }
 }
 
@@ -403,6 +442,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     const int nt = p.K * ESZ / 128;
     stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, 0, smem, wave, lane);
     stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, 0, smem + T::A_BYTES, wave, lane);
+    float2* tile_stats = reinterpret_cast<float2*>(smem + T::LDS_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
+    if (EK == 2) ln_tile_stats<T>(p, m0, tile_stats);                      // visible to every wave after the K loop's barriers
 
     const int fr = lane & 15;   // fragment row (m for the A^T operand, n for the W operand)
     const int fq = lane >> 4;   // 16-B k-chunk inside a 32-deep MFMA step
@@ -456,7 +497,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
             }
         }
     }
-    gemm_epilogue_family<T, EK>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq);
+    gemm_epilogue_family<T, EK>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
 }
 
 }  // namespace ivit

@@ -31,11 +31,10 @@ struct GemmParams {
     const float* rowadd; int ldra;  // EPI_BIAS_ROWADD_F32: [grp_out, N] table (position embedding)
     int grp_in, grp_out, grp_off;   // row remap m -> (m / grp_in) * grp_out + grp_off + m % grp_in
     // LayerNorm fold.  Row statistics travel between two GEMMs as per-row, per-64-column (sum, M2) pairs:
-    // EPI_BIAS_RESID_STATS writes ln_part[row][column / 64] and xb; ivit_ln_finalize folds a row's pairs in slot
-    // order (exact two-pass statistics, independent of who wrote them and when) into ln_stats[row] = (mean, rstd),
-    // which EPI_LNFOLD_* reads.
+    // EPI_BIAS_RESID_STATS writes ln_part[row][column / 64] and xb; an EPI_LNFOLD_* kernel folds the pairs of its
+    // tile's rows in slot order (exact two-pass statistics, independent of who wrote them and when) at its start.
     float2* ln_part;                // EPI_BIAS_RESID_STATS: [rows][GEMM_LN_SLOTS], written
-    const float2* ln_stats;         // EPI_LNFOLD_*: [rows] finished (mean, rstd), read
+    const float2* ln_stats;         // EPI_LNFOLD_*: [rows] finished (mean, rstd) (ivit_row_stats), or nullptr: fold ln_part
     bf16_t* xb; int ldxb;           // EPI_BIAS_RESID_STATS: bf16 copy of the new residual rows
     const float* ln_s;              // EPI_LNFOLD_*: s[n] = sum_k W'[n][k]          (bias = c[n])
     float ln_eps; int ln_dim;       // EPI_LNFOLD_*: LayerNorm epsilon and width (= K of this GEMM)
@@ -94,7 +93,6 @@ constexpr int GEMM_LN_SLOTS = 32;   // 64-column statistics slots per row (dim <
 hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, const float* gamma, const float* beta, const float* bias,
                                   bf16_t* wf, float* s_out, float* c_out, hipStream_t s);
 hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* stats, float eps, hipStream_t s);
-hipError_t launch_ln_finalize(const float2* part, int rows, int dim, float eps, float2* stats, hipStream_t s);
 // strided row gather: out[i,:] = in[i*row_stride, :dim]  (the `cls` node)
 hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, int rows, int dim, hipStream_t s);
 // f32 [rows, cols] -> bf16 [rows, ldo] (columns >= cols zero)

@@ -117,7 +117,7 @@ const char* gemm_variant_name(int v) {
 }
 
 template <class T, class K>
-static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream) {
+static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream, int extra_lds = 0) {
     // once per kernel (all kernels share one function-pointer type, so the bookkeeping is by address; one process
     // drives one GPU)
     static std::mutex mu;
@@ -125,13 +125,13 @@ static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream)
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!configured.count(reinterpret_cast<const void*>(kernel))) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES + extra_lds);
             if (e != hipSuccess) return e;
             configured.insert(reinterpret_cast<const void*>(kernel));
         }
     }
     const int tiles = ceil_div(p.M, T::BM) * ceil_div(p.N, T::BN);
-    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(T::THREADS), T::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(T::THREADS), T::LDS_BYTES + extra_lds, stream, p);
     return hipGetLastError();
 }
 
@@ -211,11 +211,11 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
     if (family) {   // LayerNorm-fold epilogues: their own instantiations of the three product tiles
         if (p.grp_in != 0) return hipErrorInvalidValue;
         if (family == 1 && (!p.ln_part || !p.resid || !p.xb || (p.ldxb % 4))) return hipErrorInvalidValue;
-        if (family == 2 && (!p.ln_stats || !p.ln_s)) return hipErrorInvalidValue;
-        switch (variant) {
-            case GEMM_TILE_128: return family == 1 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_rs, p, stream) : launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_lf, p, stream);
-            case GEMM_TILE_160: return family == 1 ? launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_rs, p, stream) : launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_lf, p, stream);
-            case GEMM_TILE_256S: return family == 1 ? launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_rs, p, stream) : launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_lf, p, stream);
+        if (family == 2 && ((!p.ln_stats && !p.ln_part) || !p.ln_s || p.ln_dim <= 0 || p.ln_dim > 64 * GEMM_LN_SLOTS)) return hipErrorInvalidValue;
+        switch (variant) {   // _lf kernels keep (mean, rstd) of their tile's rows in BM * 8 bytes of LDS behind the operand stages
+            case GEMM_TILE_128: return family == 1 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_rs, p, stream) : launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_lf, p, stream, Tile128::BM * 8);
+            case GEMM_TILE_160: return family == 1 ? launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_rs, p, stream) : launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_lf, p, stream, Tile160::BM * 8);
+            case GEMM_TILE_256S: return family == 1 ? launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_rs, p, stream) : launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_lf, p, stream, Tile256P::BM * 8);
             default: return hipErrorInvalidValue;
         }
     }

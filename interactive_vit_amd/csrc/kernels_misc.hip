@@ -363,39 +363,6 @@ hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* 
     return hipGetLastError();
 }
 
-// Folds the per-64-column (sum, M2) pairs a residual GEMM left per row (EPI_BIAS_RESID_STATS) into (mean, rstd):
-// Chan's combination in slot order - exact two-pass statistics, the same bits whatever tile shape wrote the pairs.
-// One thread per row.
-__global__ __launch_bounds__(256) void ivit_ln_finalize(const float2* __restrict__ part, int rows, int dim, float eps, float2* __restrict__ stats) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    const int nslots = (dim + 63) >> 6;
-    const float4* pr = reinterpret_cast<const float4*>(part + (size_t)row * GEMM_LN_SLOTS);
-    float4 raw[GEMM_LN_SLOTS / 2];
-#pragma unroll
-    for (int l = 0; l < GEMM_LN_SLOTS / 2; ++l) raw[l] = (2 * l < nslots) ? pr[l] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float mean = 0.f, m2 = 0.f, na = 0.f;
-#pragma unroll
-    for (int s2 = 0; s2 < GEMM_LN_SLOTS; ++s2) {
-        const int nk = max(0, min(64, dim - s2 * 64));
-        if (s2 < nslots && nk > 0) {
-            const float sm = (s2 & 1) ? raw[s2 >> 1].z : raw[s2 >> 1].x, mm = (s2 & 1) ? raw[s2 >> 1].w : raw[s2 >> 1].y;
-            const float nb = (float)nk, nn = na + nb, d = sm / nb - mean;
-            mean += d * (nb / nn);
-            m2 += mm + d * d * (na * nb / nn);
-            na = nn;
-        }
-    }
-    stats[row] = make_float2(mean, 1.0f / sqrtf(m2 / (float)dim + eps));
-}
-
-hipError_t launch_ln_finalize(const float2* part, int rows, int dim, float eps, float2* stats, hipStream_t s) {
-    if (dim <= 0 || dim > 64 * GEMM_LN_SLOTS) return hipErrorInvalidValue;
-    if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ivit_ln_finalize, dim3(ceil_div(rows, 256)), dim3(256), 0, s, part, rows, dim, eps, stats);
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------- gather / convert
 __global__ void ivit_gather_rows(const float* __restrict__ in, int64_t row_stride, float* __restrict__ out, int rows, int dim) {
     const int d4 = dim >> 2;
