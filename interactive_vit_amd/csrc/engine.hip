@@ -164,7 +164,7 @@ struct ivit_engine {
     // sequence of a (stage range, batch) is captured once and replayed.  IVIT_GRAPHS=0 disables.
     bool graphs_on = true;
     // LayerNorm fold (bf16 data path; IVIT_FOLD_LN=0 keeps the LayerNorm kernel): see run_layer
-    bool fold_ln = false, fold_ready = false;
+    bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
     float2 *ln_part = nullptr, *ln_stats = nullptr;
     int graph_max_batch = 4;
     std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;   // (begin, end, batch, which buffer is the input)
@@ -257,6 +257,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         e->graphs_on = !(gr && atoi(gr) == 0);
         const char* fl = getenv("IVIT_FOLD_LN");
         e->fold_ln = !(fl && atoi(fl) == 0) && cfg->precision == IVIT_PRECISION_BF16 && cfg->dim <= 64 * GEMM_LN_SLOTS;
+        e->fold_always = fl && atoi(fl) == 2;
         if (e->split < 1 || e->split > ivit_engine::MAX_SPLIT) e->split = 1;
         for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
             if (hipStreamCreateWithFlags(&e->aux_stream[i], hipStreamNonBlocking) != hipSuccess ||
@@ -537,7 +538,7 @@ static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, in
 // workgroup per CU) the exposed epilogue costs more than the LayerNorm kernels it saves (-1...-2 %), so those calls
 // keep the LayerNorm kernel.  Same weights, decided per call from the token-row count.
 static bool fold_for_rows(const ivit_engine* e, int M) {
-    return e->fold_ln && !gemm_prefers_256(M, e->D, e->D);
+    return e->fold_ln && (e->fold_always || !gemm_prefers_256(M, e->D, e->D));
 }
 
 // bf16 layer; amax4 != nullptr (calibration): record max|.| of the four GEMM-input tensors.
