@@ -241,7 +241,8 @@ def main():
             traffic = None
         roofline = {"bound": "mfma",
                     "kernel": ("ivit_gemm_fp8_{160x128,256x256_stag}x128" if args.precision == "fp8" else
-                               "ivit_gemm_bf16_{160x128,256x256_stag}x64") + " (all GEMM launches of the step; tile picked per shape)",
+                               "ivit_gemm_bf16_{160x128,256x256_stag}x64[_rs|_lf]") + " (all GEMM launches of the step; tile picked per shape"
+                              + ("; _lf / _rs = the LayerNorm-fold epilogues, which carry the LayerNorm work" if (args.precision == "bf16" and eng.ln_fold_for(B)) else "") + ")",
                     "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_per_step": g["launches"] // args.steps, "avg_launch_us": round(avg_us, 2),
@@ -291,7 +292,8 @@ def main():
                        "collective_overlap": ("async on RCCL's stream behind the next step's compute, drained inside the timed region" if overlap else "in line") if use_dist else None,
                        "batch_per_gpu": B, "global_batch": total, "tokens": cfg.tokens,
                        "gflop_per_image": round(flops_img / 1e9, 3), "parallelism": f"dp{world}",
-                       "weights": "random init N(0,0.02^2) seed 0"},
+                       "weights": "random init N(0,0.02^2) seed 0",
+                       "layernorm": "folded into the consuming GEMMs" if (args.precision == "bf16" and eng.ln_fold_for(B)) else "kernel"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         sys.stdout.flush()
