@@ -358,21 +358,32 @@ __device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float
         } else {
             const int nslots = (p.ln_dim + 63) >> 6;
             const float4* pr = reinterpret_cast<const float4*>(p.ln_part + (size_t)m * GEMM_LN_SLOTS);
-            float mean = 0.f, m2 = 0.f, na = 0.f;
-            for (int s0 = 0; s0 < nslots; s0 += 12) {
+            float mean = 0.f, m2 = 0.f;
+            // Chan's update for slot k (0-based) when every earlier slot is a full 64 columns:
+            //   d = mean_k - mean;  mean += d * n_k / (64 k + n_k);  M2 += M2_k + d^2 * 64 k n_k / (64 k + n_k)
+            // fully unrolled, so for the full slots (n_k = 64) the three ratios are compile-time constants - the
+            // loop with run-time divisions cost the MLP-up GEMM 7 us at the start of its tiles
+#pragma unroll
+            for (int s0 = 0; s0 < GEMM_LN_SLOTS; s0 += 12) {
+                if (s0 >= nslots) break;                      // uniform
                 float4 raw[6];
 #pragma unroll
                 for (int l = 0; l < 6; ++l) raw[l] = pr[min((s0 >> 1) + l, GEMM_LN_SLOTS / 2 - 1)];
 #pragma unroll
                 for (int q = 0; q < 12; ++q) {
-                    const int s2 = s0 + q;
-                    const int nk = max(0, min(64, p.ln_dim - s2 * 64));
-                    if (s2 < nslots && nk > 0) {
-                        const float sm = (q & 1) ? raw[q >> 1].z : raw[q >> 1].x, mm = (q & 1) ? raw[q >> 1].w : raw[q >> 1].y;
-                        const float nb = (float)nk, nn = na + nb, d = sm / nb - mean;
+                    constexpr float inv64 = 1.0f / 64.0f;
+                    const int s2 = s0 + q;                     // compile-time after unrolling
+                    if (s2 >= GEMM_LN_SLOTS || s2 >= nslots) continue;
+                    const float sm = (q & 1) ? raw[q >> 1].z : raw[q >> 1].x, mm = (q & 1) ? raw[q >> 1].w : raw[q >> 1].y;
+                    const int nk = min(64, p.ln_dim - s2 * 64);
+                    if (nk == 64) {
+                        const float d = fmaf(sm, inv64, -mean);
+                        mean = fmaf(d, 1.0f / (float)(s2 + 1), mean);
+                        m2 = fmaf(d * d, 64.0f * (float)s2 / (float)(s2 + 1), m2 + mm);
+                    } else {                                   // the last, ragged slot of a width that is not a multiple of 64
+                        const float nb = (float)nk, na = 64.0f * (float)s2, nn = na + nb, d = sm / nb - mean;
                         mean = fmaf(d, nb / nn, mean);
                         m2 = fmaf(d * d, na * nb / nn, m2 + mm);
-                        na = nn;
                     }
                 }
             }

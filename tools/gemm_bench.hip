@@ -37,6 +37,7 @@ int main(int argc, char** argv) {
         {"mlp1  ", Mfull, 3072, 768, EPI_BIAS_GELU_BF16}, {"mlp2  ", Mfull, 768, 3072, EPI_BIAS_RESID_F32},
         {"patch ", 64 * 196, 768, 768, EPI_BIAS_F32}, {"mlp1ng", Mfull, 3072, 768, EPI_BIAS_BF16},
         {"projRS", Mfull, 768, 768, EPI_BIAS_RESID_STATS}, {"mlp2RS", Mfull, 768, 3072, EPI_BIAS_RESID_STATS},
+        {"qkvLF ", Mfull, 2304, 768, EPI_LNFOLD_BF16}, {"mlp1LF", Mfull, 3072, 768, EPI_LNFOLD_GELU_BF16},
     };
     const char* set = getenv("IVIT_SHAPES");   // "vith": the ViT-H/14 layer shapes (dim 1280, mlp 5120)
     if (set && !strcmp(set, "vith"))
@@ -82,6 +83,7 @@ int main(int argc, char** argv) {
         p.A = dA; p.lda = s.K; p.W = dW; p.ldw = s.K; p.M = s.M; p.N = s.N; p.K = s.K; p.bias = db; p.epi = s.epi;
         p.out = dout; p.ldo = s.N; p.resid = dres; p.ldr = s.N; p.debug = debug;
         p.ln_part = dpart; p.xb = dxb; p.ldxb = s.N;
+        p.ln_s = db; p.ln_eps = 1e-6f; p.ln_dim = s.K;   // EPI_LNFOLD_*: statistics folded from dpart (timing only; the engine tests check values)
         // correctness on sampled rows (epilogue F32 so the values are comparable)
         std::vector<int> rows(NR);
         for (int i = 0; i < NR; ++i) rows[i] = (int)((long long)i * (s.M - 1) / (NR - 1));
