@@ -205,3 +205,36 @@ def test_preprocess_oracle_is_the_torchvision_preset():
     assert torch.allclose(a, b, atol=1e-6)
     # unbatched form through the node dispatcher
     assert torch.equal(vit_oracle.run_node_any("preprocess", x[0], None, cfg), a[0])
+
+
+def test_layernorm_fold_is_an_equally_good_bf16_evaluation():
+    """The engine's default on the bf16 path folds each LayerNorm into the GEMM that consumes it
+    (oracle: vit_oracle.folded_linear / LN_FOLD).  In exact arithmetic the folded form IS the LayerNorm followed by the
+    linear layer; with the engine's bf16 rounding points it is as far from the f32 forward as the unfolded form."""
+    from interactive_vit_amd.vit_config import test_config
+    from oracle import vit_oracle as vo
+    cfg = test_config()
+    sd = init_weights(cfg, seed=3, mode="rich")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((2, cfg.tokens, cfg.dim), generator=g, dtype=torch.float64) * 1.5 + 0.2
+    pre = vo.layer_prefix(0)
+    w, b = sd[pre + "mlp.0.weight"].double(), sd[pre + "mlp.0.bias"].double()
+    gamma, beta = sd[pre + "ln_2.weight"].double(), sd[pre + "ln_2.bias"].double()
+    exact = vo.layer_norm(x, gamma, beta, cfg.ln_eps) @ w.t() + b
+    # algebra: without any rounding the fold reproduces LayerNorm + linear to f64 round-off
+    mu = x.mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((x - mu) ** 2).mean(-1, keepdim=True) + cfg.ln_eps)
+    wf = w * gamma[None, :]
+    assert torch.allclose(rstd * (x @ wf.t() - mu * wf.sum(1)) + (w @ beta + b), exact, rtol=1e-10, atol=1e-10)
+    # with the engine's rounding points: same order of error as rounding LayerNorm's output
+    folded = vo.folded_linear(x, w, b, gamma, beta, cfg.ln_eps)
+    unfolded = vo.rnd(vo.layer_norm(x, gamma, beta, cfg.ln_eps), True) @ vo.rnd(w, True).t() + b
+    den = exact.abs().max()
+    e_fold, e_unf = float((folded - exact).abs().max() / den), float((unfolded - exact).abs().max() / den)
+    assert e_fold <= 5e-3 and e_unf <= 5e-3 and e_fold <= 2.0 * e_unf + 1e-4, (e_fold, e_unf)
+    # and a whole layer in either mode stays inside the per-node bound against the plain forward
+    ref = vo.encoder_layer(x, sd, 0, cfg)
+    for fold in (False, True):
+        vo.LN_FOLD = fold
+        err = float((vo.encoder_layer(x, sd, 0, cfg, emulate=True) - ref).abs().max() / ref.abs().max())
+        assert err <= 5e-3, (fold, err)
