@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define IVIT_ABI_VERSION 5
+#define IVIT_ABI_VERSION 6
 
 #define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
 #define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
@@ -92,6 +92,16 @@ int ivit_weights_ready(ivit_engine* e);
  * kernel.  Both forms are bf16 evaluations of the same f32 contract with different rounding points; the parity tests
  * ask which one the oracle's rounding-aware mode has to mirror. */
 int ivit_ln_fold(const ivit_engine* e, int batch);
+
+/* Guard of the LayerNorm fold for a weight set.  The folded GEMM multiplies the UNCENTRED 16-bit copy of the residual
+ * stream, so its operand-rounding noise is sqrt(1 + (mean/std)^2) times the unfolded form's, mean / std taken per
+ * token row of the LayerNorm input - small for the seeded weights of the tests, not guaranteed for a user-supplied
+ * checkpoint (reference plugins load whatever state dict they are given, static/models/vgg16.py:12-14).  This entry
+ * runs one forward of `batch` sample images (`in`: device f32 [B,3,S,S] in [0,1]) with LayerNorm kernels, records
+ * max |mean| / std over every LayerNorm input row of every layer into *max_ratio (optional), and keeps the fold for
+ * this engine only if that maximum is <= threshold (0.5: at most 12 % more rounding noise); otherwise every later call
+ * uses the LayerNorm kernels (ivit_ln_fold then answers 0).  Synchronises `stream`. */
+int ivit_ln_fold_calibrate(ivit_engine* e, int batch, const void* in, float threshold, float* max_ratio, void* stream);
 
 /* Replaces: Model.compute -> sub(x)  (reference main/context.py:79-88) for a run of nodes.
  * Host-buffer form (interactive path: the request tensors are CPU f32, main/message.py:58):
@@ -153,6 +163,19 @@ int ivit_fp8_scales(ivit_engine* e, float* out, int capacity);
  * normalise != 0 applies the transform first (the fused path), 0 unfolds the input as is. */
 int ivit_debug_unfold(ivit_engine* e, int batch, const void* in, void* out, int normalise, void* stream);
 
+/* Inspection entries used by the per-GEMM parity tests.  An encoder layer is seven steps: 1 LayerNorm 1 (with the
+ * LayerNorm fold: the 16-bit operand copy of x the QKV GEMM consumes), 2 QKV projection, 3 attention, 4 out-projection
+ * (+ residual), 5 LayerNorm 2 (fold: nothing new - the copy the out-projection left), 6 MLP up (+ GELU), 7 MLP down
+ * (+ residual).  ivit_debug_layer_tap runs layer `layer` on `in` (device f32 [B,N,D]) up to and including step `tap` and
+ * copies that step's output AS STORED - e4m3 bytes, bf16 / f16 halves or f32, rows of *row_bytes bytes, *elem_bytes per
+ * element - to `out` (device): the exact operand bytes the next GEMM multiplies, so that a test can gate every GEMM on
+ * identical quantised inputs.  ivit_debug_weight_fp8 copies a quantised matrix of the fp8 path (which: 0 in_proj,
+ * 1 out_proj, 2 mlp.0, 3 mlp.3; [rows][*ld] bytes) and its per-row scales to HOST memory. */
+int ivit_debug_layer_tap(ivit_engine* e, int layer, int batch, const void* in, int tap, void* out, int64_t out_capacity_bytes,
+                         int64_t* row_bytes, int* elem_bytes, void* stream);
+int ivit_debug_weight_fp8(ivit_engine* e, int layer, int which, void* out_bytes, int64_t out_capacity_bytes, float* out_rowscale,
+                          int rowscale_capacity, int* rows, int* cols, int* ld);
+
 /* Per-kernel-class device timing (HIP events on the launch stream), for bench.py's roofline line.
  * While enabled every launch of a class is bracketed by an event pair; ivit_profile_read
  * synchronises, then returns accumulated milliseconds, launch count and algorithmic FLOPs and
@@ -163,6 +186,14 @@ int         ivit_profile_class_count(void);
 const char* ivit_profile_class_name(int cls);
 int         ivit_profile_read(ivit_engine* e, int cls, double* ms, int64_t* launches,
                               double* flops, double* bytes);
+/* The same measurements per launch site, named "role:kernel" - e.g. "mlp1:ivit_gemm_bf16_160x128x64_lf",
+ * "qkv:ivit_gemm_bf16_256x256x64_stag", "attention:attention" - for the per-kernel roofline list of bench.py
+ * and for the tests that assert WHICH kernel a configuration dispatches (the tile is picked per shape).
+ * ivit_profile_kernel_count: distinct sites seen since ivit_profile_reset (-1: null engine);
+ * ivit_profile_kernel_read: copies the name (NUL-terminated, truncated to name_capacity) and the totals of site `index`. */
+int         ivit_profile_kernel_count(ivit_engine* e);
+int         ivit_profile_kernel_read(ivit_engine* e, int index, char* name, int name_capacity, double* ms,
+                                     int64_t* launches, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }

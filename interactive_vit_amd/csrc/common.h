@@ -61,25 +61,24 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// erf(x) by Abramowitz & Stegun 7.1.26: 1 - (a1 t + ... + a5 t^5) exp(-x^2), t = 1/(1 + p|x|);
-// |error| <= 1.5e-7 exact, <= 6e-7 evaluated in f32 - three orders below the bf16 rounding of the GELU output it feeds -
-// at ~14 VALU ops (one v_rcp_f32, one v_exp_f32) instead of the branchy libm erff, which cost 22 %
-// of the MLP-up GEMM when used in its epilogue.
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
-    return copysignf(fmaf(-poly, e, 1.0f), x);
-}
-
-// erf-form GELU (torch.nn.GELU() default): 0.5 x (1 + erf(x / sqrt 2))
+// erf-form GELU (torch.nn.GELU() default), 0.5 x (1 + erf(x / sqrt 2)), with erf by Abramowitz & Stegun 7.1.26
+// (1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p |z|); |error| <= 1.5e-7), written for the GEMM epilogues, where
+// VALU issue slots are what the interleaved MFMA loop runs out of first:
+//     gelu(x) = max(x, 0) - |x| P(t) exp(-x^2 / 2),    t = 1 / (1 + (p / sqrt 2) |x|),   P = (a1 t + ... + a5 t^5) / 2
+// 13 VALU instructions (one v_rcp_f32, one v_exp_f32) instead of the 16 of "0.5 x (1 + copysign(erf(|z|), z))";
+// <= 3.4e-7 absolute from the f64 GELU over |x| <= 9 (three orders below the bf16 rounding of the output it feeds).
+// The branchy libm erff cost 22 % of the MLP-up GEMM when used in its epilogue.
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164188826636045f, ax, 1.0f));
+    const float w = x * 0.8493218002880191f;                       // exp(-x^2 / 2) = exp2(-(x sqrt(log2(e) / 2))^2)
+    const float e = __builtin_amdgcn_exp2f(-(w * w));
+    float poly = fmaf(0.5307027145f, t, -0.7265760135f);
+    poly = fmaf(poly, t, 0.7107068705f);
+    poly = fmaf(poly, t, -0.142248368f);
+    poly = fmaf(poly, t, 0.127414796f);
+    const float q = poly * (t * ax);
+    return fmaf(-q, e, fmaxf(x, 0.0f));
 }
 
 // The unfold bookkeeping, shared by host (ivit_unfold_offset) and device (unfold kernel):

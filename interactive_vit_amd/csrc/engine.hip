@@ -165,6 +165,9 @@ struct ivit_engine {
     bool graphs_on = true;
     // LayerNorm fold (bf16 data path; IVIT_FOLD_LN=0 keeps the LayerNorm kernel): see run_layer
     bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
+    bool fold_blocked = false;      // ivit_ln_fold_calibrate found rows with |mean| / std above its threshold: keep the LayerNorm kernels
+    float* ratio_dev = nullptr;     // calibration scratch: max |mean| / std seen (non-null only while calibrating)
+    bool ratio_on = false;
     float2 *ln_part = nullptr, *ln_stats = nullptr;
     int graph_max_batch = 4;
     std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;   // (begin, end, batch, which buffer is the input)
@@ -176,8 +179,12 @@ struct ivit_engine {
 
     // profiling
     bool prof_on = false;
-    struct Span { hipEvent_t a, b; };
+    struct Span { hipEvent_t a, b; int tag; };
     std::vector<Span> spans[PC_COUNT];
+    std::vector<std::string> tag_names;            // "role:kernel" of every distinct launch site seen while profiling
+    std::vector<int> tag_class;
+    std::vector<double> tag_flops, tag_bytes;
+    std::map<std::string, int> tag_index;
     std::vector<hipEvent_t> event_pool;
     double prof_flops[PC_COUNT] = {0, 0, 0, 0}, prof_bytes[PC_COUNT] = {0, 0, 0, 0};
 };
@@ -200,9 +207,10 @@ static int alloc_matrix(ivit_engine* e, Matrix* m, int rows, int cols) {
 
 static int alloc_vec(ivit_engine* e, float** v, int64_t n) { return dev_alloc(e, (void**)v, (size_t)n * sizeof(float), true); }
 
-struct ProfScope {   // brackets one launch with events when profiling is on
-    ivit_engine* e; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ProfScope(ivit_engine* e_, int cls_, hipStream_t s_, double flops, double bytes) : e(e_), cls(cls_), s(s_), on(e_->prof_on) {
+struct ProfScope {   // brackets one launch with events when profiling is on; `role` / `kernel` name the launch for the per-kernel table
+    ivit_engine* e; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on; int tag = -1;
+    ProfScope(ivit_engine* e_, int cls_, hipStream_t s_, double flops, double bytes, const char* role = nullptr, const char* kernel = nullptr)
+        : e(e_), cls(cls_), s(s_), on(e_->prof_on) {
         if (!on) return;
         auto get = [&]() {
             hipEvent_t ev = nullptr;
@@ -214,12 +222,21 @@ struct ProfScope {   // brackets one launch with events when profiling is on
         if (!a || !b) { on = false; return; }
         e->prof_flops[cls] += flops;
         e->prof_bytes[cls] += bytes;
+        const std::string name = std::string(role ? role : k_prof_names[cls]) + ":" + (kernel ? kernel : k_prof_names[cls]);
+        auto it = e->tag_index.find(name);
+        if (it == e->tag_index.end()) {
+            tag = (int)e->tag_names.size();
+            e->tag_index.emplace(name, tag);
+            e->tag_names.push_back(name); e->tag_class.push_back(cls); e->tag_flops.push_back(0.0); e->tag_bytes.push_back(0.0);
+        } else tag = it->second;
+        e->tag_flops[tag] += flops;
+        e->tag_bytes[tag] += bytes;
         (void)hipEventRecord(a, s);
     }
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(b, s);
-        e->spans[cls].push_back({a, b});
+        e->spans[cls].push_back({a, b, tag});
     }
 };
 
@@ -465,7 +482,7 @@ struct LnFold {
 
 static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, const Matrix& W, int M, const float* bias,
                     int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, const float* rowadd = nullptr,
-                    int ldra = 0, int grp_in = 0, int grp_out = 0, int grp_off = 0, const LnFold* lf = nullptr) {
+                    int ldra = 0, int grp_in = 0, int grp_out = 0, int grp_off = 0, const LnFold* lf = nullptr, const char* role = "gemm") {
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld;
     p.bias = bias; p.epi = epi; p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr;
@@ -476,7 +493,7 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
     const double flops = 2.0 * M * (double)W.rows * W.cols;
     const double bytes = 2.0 * ((double)M * W.cols + (double)W.rows * W.cols) + (double)M * W.rows * (bf_out ? 2 : 4) +
                          (resid_in ? 4.0 * M * W.rows : 0.0) + (epi == EPI_BIAS_RESID_STATS ? 2.0 * M * W.rows : 0.0);
-    ProfScope ps(e, PC_GEMM, st, flops, bytes);
+    ProfScope ps(e, PC_GEMM, st, flops, bytes, role, gemm_kernel_name(p));
     HIP_TRY(launch_gemm(p, st));
     return 0;
 }
@@ -491,7 +508,7 @@ static int run_layernorm(ivit_engine* e, hipStream_t st, const float* x, int64_t
 
 // fp8 operands: A [M, ld8] bytes, W = quantised matrix; epilogue dequantises with q.colscale
 static int run_gemm_fp8(ivit_engine* e, hipStream_t st, const unsigned char* A, int lda, const Matrix8& q, int M, const float* bias,
-                        int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, float out_scale = 1.0f) {
+                        int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, float out_scale = 1.0f, const char* role = "gemm") {
     GemmParams p{};
     p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda; p.W = reinterpret_cast<const bf16_t*>(q.p); p.ldw = q.ld;
     p.M = M; p.N = q.rows; p.K = q.ld; p.colscale = q.colscale; p.out_scale = out_scale;
@@ -500,7 +517,7 @@ static int run_gemm_fp8(ivit_engine* e, hipStream_t st, const unsigned char* A, 
     const double out_b = (epi == EPI_BIAS_GELU_FP8) ? 1.0 : (epi == EPI_BIAS_BF16 ? 2.0 : 4.0);
     const double bytes = ((double)M * q.cols + (double)q.rows * q.cols) + (double)M * q.rows * out_b +
                          (epi == EPI_BIAS_RESID_F32 ? 4.0 * M * q.rows : 0.0);
-    ProfScope ps(e, PC_GEMM, st, flops, bytes);
+    ProfScope ps(e, PC_GEMM, st, flops, bytes, role, gemm_fp8_kernel_name(p));
     HIP_TRY(launch_gemm_fp8(p, st));
     return 0;
 }
@@ -519,17 +536,27 @@ static int run_attention(ivit_engine* e, const Ws& w, hipStream_t st, int B, uns
     return 0;
 }
 
+// Taps (ivit_debug_layer_tap): a layer is seven steps - 1 LN1 (or the operand copy the QKV GEMM consumes), 2 QKV,
+// 3 attention, 4 out-projection, 5 LN2 (or the operand copy), 6 MLP up, 7 MLP down; `tap` = k stops after step k.
+enum { TAP_NONE = 0, TAP_H1 = 1, TAP_QKV = 2, TAP_ATT = 3, TAP_PROJ = 4, TAP_H2 = 5, TAP_U = 6, TAP_OUT = 7 };
+
 // fp8 data path of one encoder layer (IVIT_PRECISION_FP8, after calibration)
-static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B) {
+static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B, int tap = TAP_NONE) {
     const int D = e->D, M = B * e->N;
     LayerWeights& lw = e->layers[li];
     if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, nullptr, nullptr, w.h8, 1.0f / lw.s_h1)) return 1;
-    if (run_gemm_fp8(e, st, w.h8, e->ld8d, lw.q_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
+    if (tap == TAP_H1) return 0;
+    if (run_gemm_fp8(e, st, w.h8, e->ld8d, lw.q_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, 1.0f, "qkv")) return 1;
+    if (tap == TAP_QKV) return 0;
     if (run_attention(e, w, st, B, w.att8, 1.0f / lw.s_att)) return 1;
-    if (run_gemm_fp8(e, st, w.att8, e->ld8d, lw.q_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
+    if (tap == TAP_ATT) return 0;
+    if (run_gemm_fp8(e, st, w.att8, e->ld8d, lw.q_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D, 1.0f, "proj")) return 1;
+    if (tap == TAP_PROJ) return 0;
     if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, nullptr, nullptr, w.h8, 1.0f / lw.s_h2)) return 1;
-    if (run_gemm_fp8(e, st, w.h8, e->ld8d, lw.q1, M, lw.b1, EPI_BIAS_GELU_FP8, w.u8, e->ld8m, nullptr, 0, 1.0f / lw.s_u)) return 1;
-    if (run_gemm_fp8(e, st, w.u8, e->ld8m, lw.q2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
+    if (tap == TAP_H2) return 0;
+    if (run_gemm_fp8(e, st, w.h8, e->ld8d, lw.q1, M, lw.b1, EPI_BIAS_GELU_FP8, w.u8, e->ld8m, nullptr, 0, 1.0f / lw.s_u, "mlp1")) return 1;
+    if (tap == TAP_U) return 0;
+    if (run_gemm_fp8(e, st, w.u8, e->ld8m, lw.q2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D, 1.0f, "mlp2")) return 1;
     return 0;
 }
 
@@ -538,7 +565,7 @@ static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, in
 // workgroup per CU) the exposed epilogue costs more than the LayerNorm kernels it saves (-1...-2 %), so those calls
 // keep the LayerNorm kernel.  Same weights, decided per call from the token-row count.
 static bool fold_for_rows(const ivit_engine* e, int M) {
-    return e->fold_ln && (e->fold_always || !gemm_prefers_256(M, e->D, e->D));
+    return e->fold_ln && !e->fold_blocked && (e->fold_always || !gemm_prefers_256(M, e->D, e->D));
 }
 
 // bf16 layer; amax4 != nullptr (calibration): record max|.| of the four GEMM-input tensors.
@@ -550,12 +577,24 @@ static bool fold_for_rows(const ivit_engine* e, int M) {
 // `stats_in`: x's statistics / bf16 copy already exist (the previous layer's MLP-down GEMM wrote them);
 // `stats_out`: a layer follows in this call, so this layer's MLP-down GEMM writes them for it.
 static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B, float* amax4 = nullptr, bool stats_in = false,
-                     bool stats_out = false) {
+                     bool stats_out = false, int tap = TAP_NONE) {
     const int D = e->D, M = B * e->N, Mlp = e->cfg.mlp;
     LayerWeights& lw = e->layers[li];
+    if (e->ratio_on) {
+        // LayerNorm-fold calibration: the unfolded path below, with the |mean| / std of both LayerNorm inputs recorded
+        HIP_TRY(launch_row_mean_ratio(w.x, D, M, D, e->cfg.ln_eps, e->ratio_dev, st));
+        if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
+        if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "qkv")) return 1;
+        if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
+        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
+        HIP_TRY(launch_row_mean_ratio(w.x, D, M, D, e->cfg.ln_eps, e->ratio_dev, st));
+        if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, w.h, nullptr)) return 1;
+        if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "mlp1")) return 1;
+        return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2");
+    }
     if (!amax4 && e->cfg.precision == IVIT_PRECISION_FP8) {
         if (!e->fp8_ready) return fail("fp8 engine is not calibrated: call ivit_fp8_calibrate first");
-        return run_layer_fp8(e, w, st, li, B);
+        return run_layer_fp8(e, w, st, li, B, tap);
     }
     if (!amax4 && fold_for_rows(e, M)) {
         LnFold fold; fold.part = w.ln_part; fold.xb = w.h;
@@ -564,27 +603,38 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
             ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * D * 6.0);
             HIP_TRY(launch_row_stats(w.x, D, M, D, w.h, D, w.ln_stats, e->cfg.ln_eps, st));
         }
+        if (tap == TAP_H1) return 0;
         fold.s = lw.s_in;
-        if (run_gemm(e, st, w.h, D, lw.wf_in, M, lw.c_in, EPI_LNFOLD_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, &fold)) return 1;
+        if (run_gemm(e, st, w.h, D, lw.wf_in, M, lw.c_in, EPI_LNFOLD_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "qkv")) return 1;
+        if (tap == TAP_QKV) return 0;
         if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
-        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold)) return 1;
+        if (tap == TAP_ATT) return 0;
+        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
+        if (tap == TAP_PROJ || tap == TAP_H2) return 0;
         fold.s = lw.s_1;
         fold.stats = nullptr;                               // the out-projection's epilogue left the pairs: fold them in the consumer
-        if (run_gemm(e, st, w.h, D, lw.wf_1, M, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &fold)) return 1;
-        if (stats_out) return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold);
-        return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D);
+        if (run_gemm(e, st, w.h, D, lw.wf_1, M, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "mlp1")) return 1;
+        if (tap == TAP_U) return 0;
+        if (stats_out) return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold, "mlp2");
+        return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2");
     }
     if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.h, D, M, D, amax4 + 0, st));
-    if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
+    if (tap == TAP_H1) return 0;
+    if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "qkv")) return 1;
+    if (tap == TAP_QKV) return 0;
     if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.att, D, M, D, amax4 + 1, st));
-    if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
+    if (tap == TAP_ATT) return 0;
+    if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
+    if (tap == TAP_PROJ) return 0;
     if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, w.h, nullptr)) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.h, D, M, D, amax4 + 2, st));
-    if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp)) return 1;
+    if (tap == TAP_H2) return 0;
+    if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "mlp1")) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.u, Mlp, M, Mlp, amax4 + 3, st));
-    if (run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D)) return 1;
+    if (tap == TAP_U) return 0;
+    if (run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2")) return 1;
     return 0;
 }
 
@@ -624,11 +674,11 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
             HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 0, st));
         }
         if (end == ST_CONV + 1)
-            return run_gemm(e, st, w.patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_F32, out, D);
+            return run_gemm(e, st, w.patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_F32, out, D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "patch");
         // conv_proj + tokens fused: the GEMM epilogue scatters rows to token 1+n of each image and adds
         // the position embedding; a small kernel writes the class rows
         if (run_gemm(e, st, w.patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_ROWADD_F32,
-                     (end == ST_TOKENS + 1) ? out : w.x, D, nullptr, 0, e->pos, D, Np, N, 1)) return 1;
+                     (end == ST_TOKENS + 1) ? out : w.x, D, nullptr, 0, e->pos, D, Np, N, 1, nullptr, "patch")) return 1;
         {
             ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * D);
             HIP_TRY(launch_tokens(nullptr, e->cls_tok, e->pos, (end == ST_TOKENS + 1) ? out : w.x, B, Np, D, st));
@@ -671,7 +721,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
             if (cls_out) HIP_TRY(hipMemcpyAsync(cls_out, out, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
             return 0;
         }
-        return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes);
+        return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "head");
     }
     if (s == ST_CLS) {
         float* dst = (end == ST_CLS + 1) ? out : w.clsf;
@@ -689,7 +739,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         ProfScope ps(e, PC_OTHER, st, 0.0, 6.0 * B * D);
         HIP_TRY(launch_f32_to_bf16(cur, D, w.hc, D, B, D, st));
     }
-    return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes);
+    return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "head");
 }
 
 // workspace hand-over between calls on (possibly) different streams; caller holds e->mu
@@ -974,6 +1024,43 @@ extern "C" int ivit_fp8_calibrate(ivit_engine* e, int batch, const void* in, voi
     return 0;
 }
 
+extern "C" int ivit_ln_fold_calibrate(ivit_engine* e, int batch, const void* in, float threshold, float* max_ratio, void* stream) {
+    if (!e || !in) return fail("ivit_ln_fold_calibrate: null argument");
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    if (!(threshold > 0.f)) return fail("ivit_ln_fold_calibrate: threshold must be positive");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (require_weights(e)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (ws_acquire(e, st)) return 1;
+    float* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, sizeof(float)));
+    int rc = 0;
+    float ratio = 0.f;
+    do {
+        if (hipMemsetAsync(dev, 0, sizeof(float), st) != hipSuccess) { rc = fail("hipMemsetAsync failed"); break; }
+        const Ws w = ws_slice(e, 0);
+        if ((rc = forward_one(e, w, ST_TRANSFORM, ST_LAYER0, batch, (const float*)in, w.x, nullptr, st))) break;   // -> residual stream in w.x
+        e->ratio_dev = dev; e->ratio_on = true;
+        for (int li = 0; li < e->cfg.layers && !rc; ++li) rc = run_layer(e, w, st, li, batch);
+        e->ratio_on = false; e->ratio_dev = nullptr;
+        if (rc) break;
+        if (hipMemcpyAsync(&ratio, dev, sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = fail("reading the calibration statistic failed"); break; }
+    } while (0);
+    e->ratio_on = false; e->ratio_dev = nullptr;
+    (void)hipFree(dev);
+    if (ws_release(e, st)) return 1;
+    if (rc) return 1;
+    const bool blocked = ratio > threshold;
+    if (blocked != e->fold_blocked) {   // captured launch sequences embed the old choice
+        for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+        e->graphs.clear();
+    }
+    e->fold_blocked = blocked;
+    if (max_ratio) *max_ratio = ratio;
+    return 0;
+}
+
 extern "C" int ivit_fp8_scales(ivit_engine* e, float* out, int capacity) {
     if (!e || !out) return fail("ivit_fp8_scales: null argument");
     std::lock_guard<std::mutex> lk(e->mu);
@@ -999,6 +1086,58 @@ extern "C" int ivit_debug_unfold(ivit_engine* e, int batch, const void* in, void
     return ws_release(e, st);
 }
 
+extern "C" int ivit_debug_layer_tap(ivit_engine* e, int layer, int batch, const void* in, int tap, void* out, int64_t out_capacity_bytes,
+                                    int64_t* row_bytes, int* elem_bytes, void* stream) {
+    if (!e || !in || !out) return fail("ivit_debug_layer_tap: null argument");
+    if (layer < 0 || layer >= e->cfg.layers) return fail("layer %d outside 0..%d", layer, e->cfg.layers - 1);
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    if (tap < TAP_H1 || tap > TAP_OUT) return fail("tap %d outside 1..7", tap);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (require_weights(e)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int D = e->D, M = batch * e->N, Mlp = e->cfg.mlp;
+    const bool f8 = e->cfg.precision == IVIT_PRECISION_FP8;
+    const Ws w = ws_slice(e, 0);
+    const void* src = nullptr; int64_t rb = 0; int eb = 0;
+    switch (tap) {
+        case TAP_H1: case TAP_H2: src = f8 ? (const void*)w.h8 : (const void*)w.h; eb = f8 ? 1 : 2; rb = f8 ? e->ld8d : 2 * D; break;
+        case TAP_QKV: src = w.qkv; eb = 2; rb = 2 * 3 * D; break;
+        case TAP_ATT: src = f8 ? (const void*)w.att8 : (const void*)w.att; eb = f8 ? 1 : 2; rb = f8 ? e->ld8d : 2 * D; break;
+        case TAP_U: src = f8 ? (const void*)w.u8 : (const void*)w.u; eb = f8 ? 1 : 2; rb = f8 ? e->ld8m : 2 * Mlp; break;
+        default: src = w.x; eb = 4; rb = 4 * D; break;   // TAP_PROJ, TAP_OUT: the f32 residual stream
+    }
+    if ((int64_t)M * rb > out_capacity_bytes) return fail("ivit_debug_layer_tap: output needs %lld bytes, capacity is %lld", (long long)M * rb, (long long)out_capacity_bytes);
+    if (ws_acquire(e, st)) return 1;
+    HIP_TRY(hipMemcpyAsync(w.x, in, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+    if (run_layer(e, w, st, layer, batch, nullptr, false, false, tap)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, src, (size_t)M * rb, hipMemcpyDeviceToDevice, st));
+    if (row_bytes) *row_bytes = rb;
+    if (elem_bytes) *elem_bytes = eb;
+    return ws_release(e, st);
+}
+
+extern "C" int ivit_debug_weight_fp8(ivit_engine* e, int layer, int which, void* out_bytes, int64_t out_capacity_bytes, float* out_rowscale,
+                                     int rowscale_capacity, int* rows, int* cols, int* ld) {
+    if (!e || !out_bytes || !out_rowscale) return fail("ivit_debug_weight_fp8: null argument");
+    if (e->cfg.precision != IVIT_PRECISION_FP8) return fail("ivit_debug_weight_fp8: engine was created without IVIT_PRECISION_FP8");
+    if (layer < 0 || layer >= e->cfg.layers || which < 0 || which > 3) return fail("ivit_debug_weight_fp8: layer %d / matrix %d out of range", layer, which);
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->fp8_ready) return fail("fp8 engine is not calibrated: call ivit_fp8_calibrate first");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    LayerWeights& lw = e->layers[layer];
+    const Matrix8* qs[4] = {&lw.q_in, &lw.q_out, &lw.q1, &lw.q2};
+    const Matrix8& q = *qs[which];
+    if ((int64_t)q.rows * q.ld > out_capacity_bytes || q.rows > rowscale_capacity) return fail("ivit_debug_weight_fp8: buffers too small for %d x %d", q.rows, q.ld);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_bytes, q.p, (size_t)q.rows * q.ld, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_rowscale, q.rowscale, (size_t)q.rows * 4, hipMemcpyDeviceToHost));
+    if (rows) *rows = q.rows;
+    if (cols) *cols = q.cols;
+    if (ld) *ld = q.ld;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ profiling
 extern "C" int ivit_profile_class_count(void) { return PC_COUNT; }
 extern "C" const char* ivit_profile_class_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? k_prof_names[cls] : ""; }
@@ -1020,6 +1159,35 @@ extern "C" int ivit_profile_reset(ivit_engine* e) {
         e->spans[c].clear();
         e->prof_flops[c] = e->prof_bytes[c] = 0.0;
     }
+    e->tag_names.clear(); e->tag_class.clear(); e->tag_flops.clear(); e->tag_bytes.clear(); e->tag_index.clear();
+    return 0;
+}
+
+extern "C" int ivit_profile_kernel_count(ivit_engine* e) {
+    if (!e) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    return (int)e->tag_names.size();
+}
+
+extern "C" int ivit_profile_kernel_read(ivit_engine* e, int index, char* name, int name_capacity, double* ms, int64_t* launches,
+                                        double* flops, double* bytes) {
+    if (!e) return fail("null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (index < 0 || index >= (int)e->tag_names.size()) return fail("ivit_profile_kernel_read: index %d outside 0..%d", index, (int)e->tag_names.size() - 1);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    double total = 0.0; int64_t n = 0;
+    for (auto& sp : e->spans[e->tag_class[index]]) {
+        if (sp.tag != index) continue;
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
+        total += t; ++n;
+    }
+    if (name && name_capacity > 0) { strncpy(name, e->tag_names[index].c_str(), (size_t)name_capacity - 1); name[name_capacity - 1] = 0; }
+    if (ms) *ms = total;
+    if (launches) *launches = n;
+    if (flops) *flops = e->tag_flops[index];
+    if (bytes) *bytes = e->tag_bytes[index];
     return 0;
 }
 

@@ -430,13 +430,43 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, 
     tn = panel * group + (within - tm * width);
 }
 
+// Row bands per XCD: the linear tile order is band-major (8 bands of ~tiles_m / 8 row tiles), column panels inside a
+// band, row-major inside a panel - so the contiguous run of tiles an XCD executes (xcd_tile) stays inside one band of
+// A rows for the whole launch (A enters one L2) and sweeps the W panels.
+__device__ __forceinline__ void tile_coords_banded(int tile, int tiles_m, int tiles_n, int& tm, int& tn, int group = GEMM_GROUP_N) {
+    const int rpb = (tiles_m + 7) >> 3;
+    const int band = tile / (rpb * tiles_n);
+    const int within = tile - band * rpb * tiles_n;
+    const int rows = min(rpb, tiles_m - band * rpb);
+    tile_coords(within, rows, tiles_n, tm, tn, group);
+    tm += band * rpb;
+}
+
+#ifdef IVIT_GEMM_ABLATIONS
+#define IVIT_BODY_STAMP(slot)                                                                                 \
+    do {                                                                                                      \
+        if (p.stamps && threadIdx.x == 0) {                                                                   \
+            unsigned long long t_;                                                                            \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+            p.stamps[(size_t)blockIdx.x * 16 + (slot)] = t_;                                                  \
+        }                                                                                                     \
+    } while (0)
+#else
+#define IVIT_BODY_STAMP(slot) do { } while (0)
+#endif
+
 template <class T, bool FP8 = false, int EK = 0>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave / T::WAVES_N, wc = wave % T::WAVES_N;
+    IVIT_BODY_STAMP(0);
 
     int tm, tn;
+#ifdef IVIT_GEMM_ABLATIONS
+    if (p.order == 1) tile_coords_banded(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
+    else
+#endif
     tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
     const int m0 = tm * T::BM;
     const int n0 = tn * T::BN;
@@ -455,6 +485,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, 0, smem + T::A_BYTES, wave, lane);
     float2* tile_stats = reinterpret_cast<float2*>(smem + T::LDS_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
     if (EK == 2) ln_tile_stats<T>(p, m0, tile_stats);                      // visible to every wave after the K loop's barriers
+    IVIT_BODY_STAMP(1);
 
     const int fr = lane & 15;   // fragment row (m for the A^T operand, n for the W operand)
     const int fq = lane >> 4;   // 16-B k-chunk inside a 32-deep MFMA step
@@ -508,7 +539,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
             }
         }
     }
+    IVIT_BODY_STAMP(2);
     gemm_epilogue_family<T, EK>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
+    IVIT_BODY_STAMP(3);
+#ifdef IVIT_GEMM_ABLATIONS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IVIT_BODY_STAMP(4);
+    if (p.stamps && threadIdx.x == 0)   // which CU ran this block (per-CU timelines in tools/gemm_bench)
+        p.stamps[(size_t)blockIdx.x * 16 + 5] = ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
 }
 
 }  // namespace ivit

@@ -4,6 +4,10 @@
 
 namespace ivit {
 
+// Raises a kernel's dynamic-LDS limit once per (device, kernel): the attribute belongs to the device that is current
+// when it is set, and one process may hold engines on several devices (ivit_config.device).
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
+
 // ---------------------------------------------------------------- GEMM (kernels_gemm.hip)
 enum GemmEpilogue : int {
     EPI_BIAS_BF16 = 0,       // out(bf16)  = acc + bias
@@ -40,6 +44,7 @@ struct GemmParams {
     float ln_eps; int ln_dim;       // EPI_LNFOLD_*: LayerNorm epsilon and width (= K of this GEMM)
     int debug;                      // microbenchmark ablations only (0 in the product): 1 = no DMA in the K loop, 2 = no MFMA
     unsigned long long* stamps;     // microbenchmark builds only: per-block s_memrealtime stamps (nullptr in the product)
+    int order;                      // microbenchmark builds only: 1 = row bands per XCD (tile_coords_banded)
 };
 
 enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_VARIANTS = 8 };
@@ -52,6 +57,9 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
 int gemm_pick_variant(int M, int N, int K);
 bool gemm_prefers_256(int M, int N, int K);   // the one-workgroup-per-CU 256x256 tile is picked (many rounds of tiles)
 const char* gemm_variant_name(int v);
+// name of the kernel launch_gemm / launch_gemm_fp8 dispatches for these parameters (per-kernel profiling, dispatch tests)
+const char* gemm_kernel_name(const GemmParams& p);
+const char* gemm_fp8_kernel_name(const GemmParams& p);
 
 // ---------------------------------------------------------------- attention (kernels_attn.hip)
 struct AttnParams {
@@ -93,6 +101,8 @@ constexpr int GEMM_LN_SLOTS = 32;   // 64-column statistics slots per row (dim <
 hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, const float* gamma, const float* beta, const float* bias,
                                   bf16_t* wf, float* s_out, float* c_out, hipStream_t s);
 hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* stats, float eps, hipStream_t s);
+// atomicMax(*out, max over rows of |mean| / sqrt(var + eps)) of a [rows, dim] f32 matrix; the caller zeroes *out
+hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, float eps, float* out, hipStream_t s);
 // strided row gather: out[i,:] = in[i*row_stride, :dim]  (the `cls` node)
 hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, int rows, int dim, hipStream_t s);
 // f32 [rows, cols] -> bf16 [rows, ldo] (columns >= cols zero)

@@ -256,13 +256,8 @@ bool attention_supported(int tokens, int head_dim) {
 template <int DH, int NKF, bool ODD, bool PROBS>
 static hipError_t launch_nkf_impl(const AttnParams& p, hipStream_t stream) {
     using L = AttLayout<DH, NKF, ODD>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_attention_bf16<DH, NKF, ODD, PROBS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ivit_attention_bf16<DH, NKF, ODD, PROBS>), L::LDS_BYTES);
+    if (e != hipSuccess) return e;
     const int blocks = ceil_div(p.tokens, 16);
     // every wave gets at least one 16-query block.  (Measured at 197 keys, three 5-wave workgroups per CU -
     // which the 53-KiB ODD image allows - against two of 7-8 waves: 0.333 vs 0.307 ms per 12 launches; the

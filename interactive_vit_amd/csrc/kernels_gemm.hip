@@ -9,6 +9,7 @@
 #include <cmath>
 #include <mutex>
 #include <set>
+#include <utility>
 
 namespace ivit {
 
@@ -116,20 +117,23 @@ const char* gemm_variant_name(int v) {
     return "?";
 }
 
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> configured;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    if (configured.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) configured.insert({dev, kernel});
+    return e;
+}
+
 template <class T, class K>
 static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream, int extra_lds = 0) {
-    // once per kernel (all kernels share one function-pointer type, so the bookkeeping is by address; one process
-    // drives one GPU)
-    static std::mutex mu;
-    static std::set<const void*> configured;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!configured.count(reinterpret_cast<const void*>(kernel))) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES + extra_lds);
-            if (e != hipSuccess) return e;
-            configured.insert(reinterpret_cast<const void*>(kernel));
-        }
-    }
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), T::LDS_BYTES + extra_lds);
+    if (e != hipSuccess) return e;
     const int tiles = ceil_div(p.M, T::BM) * ceil_div(p.N, T::BN);
     hipLaunchKernelGGL(kernel, dim3(tiles), dim3(T::THREADS), T::LDS_BYTES + extra_lds, stream, p);
     return hipGetLastError();
@@ -176,11 +180,8 @@ int gemm_pick_variant(int M, int N, int K) {
 }
 
 static int device_cu_count() {
-    static int cus = 0;   // one process drives one GPU
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     return cus;
 }
 
@@ -188,13 +189,8 @@ static int device_cu_count() {
 // persistent kernel: one workgroup per CU (or per tile when there are fewer tiles than CUs)
 static hipError_t launch_persistent(const GemmParams& p, hipStream_t stream) {
     using T = Tile256P;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivit_gemm_bf16_256x256x64_persist),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ivit_gemm_bf16_256x256x64_persist), T::LDS_BYTES);
+    if (e != hipSuccess) return e;
     const int tiles = ceil_div(p.M, T::BM) * ceil_div(p.N, T::BN);
     const int grid = tiles < device_cu_count() ? tiles : device_cu_count();
     hipLaunchKernelGGL(ivit_gemm_bf16_256x256x64_persist, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, p);
@@ -244,15 +240,39 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
     return hipErrorInvalidValue;
 }
 
+static int fp8_tile(const GemmParams& p) {
+    const double t160 = std::ceil((double)ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) / 512.0) * Tile160::BM / 1.03;
+    const double t128 = std::ceil((double)ceil_div(p.M, Tile128::BM) * ceil_div(p.N, Tile128::BN) / 512.0) * Tile128::BM;
+    if (gemm_prefers_256(p.M, p.N, p.K)) return GEMM_TILE_256S;
+    return t160 <= t128 ? GEMM_TILE_160 : GEMM_TILE_128;
+}
+
+const char* gemm_fp8_kernel_name(const GemmParams& p) {
+    switch (fp8_tile(p)) {
+        case GEMM_TILE_256S: return "ivit_gemm_fp8_256x256x128_stag";
+        case GEMM_TILE_160: return "ivit_gemm_fp8_160x128x128";
+    }
+    return "ivit_gemm_fp8_128x128x128";
+}
+
+const char* gemm_kernel_name(const GemmParams& p) {
+    const int v = gemm_pick_variant(p.M, p.N, p.K);
+    const int family = p.epi == EPI_BIAS_RESID_STATS ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
+    static const char* names[3][3] = {
+        {"ivit_gemm_bf16_128x128x64", "ivit_gemm_bf16_128x128x64_rs", "ivit_gemm_bf16_128x128x64_lf"},
+        {"ivit_gemm_bf16_160x128x64", "ivit_gemm_bf16_160x128x64_rs", "ivit_gemm_bf16_160x128x64_lf"},
+        {"ivit_gemm_bf16_256x256x64_stag", "ivit_gemm_bf16_256x256x64_stag_rs", "ivit_gemm_bf16_256x256x64_stag_lf"}};
+    return names[v == GEMM_TILE_128 ? 0 : v == GEMM_TILE_160 ? 1 : 2][family];
+}
+
 hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (p.K <= 0 || p.K % 128 != 0 || !p.colscale) return hipErrorInvalidValue;
     if ((p.lda % 16) || (p.ldw % 16) || (p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
-    struct Cand { int bm, bn; double speed; };
-    const double t160 = std::ceil((double)ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) / 512.0) * Tile160::BM / 1.03;
-    const double t128 = std::ceil((double)ceil_div(p.M, Tile128::BM) * ceil_div(p.N, Tile128::BN) / 512.0) * Tile128::BM;
-    if (gemm_prefers_256(p.M, p.N, p.K)) return launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag, p, stream);
-    if (t160 <= t128) return launch_tile<Tile160>(ivit_gemm_fp8_160x128x128, p, stream);
+    switch (fp8_tile(p)) {
+        case GEMM_TILE_256S: return launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag, p, stream);
+        case GEMM_TILE_160: return launch_tile<Tile160>(ivit_gemm_fp8_160x128x128, p, stream);
+    }
     return launch_tile<Tile128>(ivit_gemm_fp8_128x128x128, p, stream);
 }
 

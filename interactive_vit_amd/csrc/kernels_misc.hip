@@ -363,6 +363,30 @@ hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* 
     return hipGetLastError();
 }
 
+// Calibration of the LayerNorm fold (ivit_ln_fold_calibrate): max over rows of |mean| / std of the LayerNorm input.
+// The folded GEMM multiplies the UNCENTRED 16-bit copy of x, so its operand-rounding noise is sqrt(1 + (mean/std)^2)
+// times the unfolded form's; this statistic decides whether a weight set keeps the fold.  One wave per row, two passes.
+__global__ __launch_bounds__(256) void ivit_row_mean_ratio(const float* __restrict__ x, int ldx, int rows, int dim, float eps,
+                                                           unsigned int* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float sum = 0.f;
+    for (int c = lane; c < dim; c += 64) sum += xr[c];
+    const float mean = wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+    for (int c = lane; c < dim; c += 64) { const float d = xr[c] - mean; sq = fmaf(d, d, sq); }
+    const float ratio = fabsf(mean) / sqrtf(wave_sum(sq) / (float)dim + eps);
+    if (lane == 0) atomicMax(out, __float_as_uint(ratio));   // non-negative floats order like their bit patterns
+}
+
+hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, float eps, float* out, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ivit_row_mean_ratio, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, rows, dim, eps, reinterpret_cast<unsigned int*>(out));
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------- gather / convert
 __global__ void ivit_gather_rows(const float* __restrict__ in, int64_t row_stride, float* __restrict__ out, int rows, int dim) {
     const int d4 = dim >> 2;

@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
     "ivit_forward_host", "ivit_forward_host_chained", "ivit_forward_device", "ivit_preprocess", "ivit_preprocess_host", "ivit_attention_map", "ivit_attention_map_host",
     "ivit_fp8_calibrate", "ivit_fp8_scales", "ivit_debug_unfold", "ivit_profile_enable",
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
+    "ivit_profile_kernel_count", "ivit_profile_kernel_read", "ivit_debug_layer_tap", "ivit_debug_weight_fp8", "ivit_ln_fold_calibrate",
 )
 
 
@@ -36,7 +37,7 @@ class IvitConfigC(ctypes.Structure):
                 ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PRECISIONS = {"bf16": 0, "fp8": 1}
 
 
@@ -91,6 +92,13 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_profile_class_name.restype = ctypes.c_char_p
         lib.ivit_profile_read.argtypes = [c_p, c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        lib.ivit_debug_layer_tap.argtypes = [c_p, c_i, c_i, c_p, c_i, c_p, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i), c_p]
+        lib.ivit_debug_weight_fp8.argtypes = [c_p, c_i, c_i, c_p, c_i64, ctypes.POINTER(ctypes.c_float), c_i, ctypes.POINTER(c_i),
+                                              ctypes.POINTER(c_i), ctypes.POINTER(c_i)]
+        lib.ivit_ln_fold_calibrate.argtypes = [c_p, c_i, c_p, ctypes.c_float, ctypes.POINTER(ctypes.c_float), c_p]
+        lib.ivit_profile_kernel_count.argtypes = [c_p]
+        lib.ivit_profile_kernel_read.argtypes = [c_p, c_i, ctypes.c_char_p, c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
+                                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         if path is None:
             _lib = lib
         return lib
@@ -287,6 +295,19 @@ class Engine:
         (include/ivit.h: ivit_ln_fold)?  What the rounding-aware oracle has to mirror for that call."""
         return bool(self.lib.ivit_ln_fold(self._h, int(batch)))
 
+    def calibrate_ln_fold(self, images: torch.Tensor, threshold: float = 0.5) -> float:
+        """Guard of the LayerNorm fold for THIS weight set (include/ivit.h: ivit_ln_fold_calibrate): one forward of
+        `images` ([B,3,S,S] in [0,1]) with LayerNorm kernels, returns max |mean| / std over all LayerNorm input rows;
+        the engine keeps the fold only if that is <= threshold."""
+        batch, _ = self._split_batch(images, 0)
+        xin = images.detach().to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        stream = torch.cuda.current_stream(xin.device).cuda_stream
+        ratio = ctypes.c_float(0.0)
+        self._check(self.lib.ivit_ln_fold_calibrate(self._h, batch, ctypes.c_void_p(xin.data_ptr()), ctypes.c_float(threshold),
+                                                    ctypes.byref(ratio), ctypes.c_void_p(stream)))
+        self.ln_fold = bool(self.lib.ivit_ln_fold(self._h, 1))
+        return float(ratio.value)
+
     def run_node(self, suffix: str, x: torch.Tensor) -> torch.Tensor:
         if suffix == "preprocess":
             return self.preprocess(x)
@@ -313,6 +334,48 @@ class Engine:
         self._check(self.lib.ivit_fp8_scales(self._h, buf, n))
         return list(buf)
 
+    @property
+    def operand_dtype(self) -> torch.dtype:
+        """The 16-bit type of the GEMM operand data path (what the oracle's rounding-aware mode has to mirror)."""
+        return torch.float16 if self.precision == "f16" else torch.bfloat16
+
+    TAPS = {"h1": 1, "qkv": 2, "att": 3, "proj": 4, "h2": 5, "u": 6, "out": 7}
+
+    def layer_tap(self, layer: int, x: torch.Tensor, tap: str) -> torch.Tensor:
+        """Runs encoder layer `layer` on x ([B,N,D] f32, CUDA) up to step `tap` and returns that step's output AS
+        STORED by the engine (include/ivit.h: ivit_debug_layer_tap): float8_e4m3fn, bfloat16 / float16 or float32
+        [B*N, width] - the exact operand bytes the next GEMM consumes."""
+        batch, _ = self._split_batch(x, 3)
+        xin = x.detach().to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        m = batch * self.cfg.tokens
+        cap = m * max(3 * self.cfg.dim * 2, self.cfg.mlp * 2, self.cfg.dim * 4)
+        raw = torch.empty(cap, dtype=torch.uint8, device=xin.device)
+        rb, eb = ctypes.c_int64(0), ctypes.c_int(0)
+        stream = torch.cuda.current_stream(xin.device).cuda_stream
+        self._check(self.lib.ivit_debug_layer_tap(self._h, layer, batch, ctypes.c_void_p(xin.data_ptr()), self.TAPS[tap],
+                                                  ctypes.c_void_p(raw.data_ptr()), cap, ctypes.byref(rb), ctypes.byref(eb), ctypes.c_void_p(stream)))
+        flat = raw[:m * rb.value].reshape(m, rb.value)
+        if eb.value == 1:
+            return flat.view(torch.float8_e4m3fn)
+        if eb.value == 2:
+            return flat.view(self.operand_dtype if tap != "qkv" or self.precision != "fp8" else torch.bfloat16)
+        return flat.view(torch.float32)
+
+    def weight_fp8(self, layer: int, which: int):
+        """(e4m3 matrix [rows, cols] as float8 CPU tensor, per-row scales f32 [rows]) of the fp8 data path
+        (which: 0 in_proj, 1 out_proj, 2 mlp.0, 3 mlp.3)."""
+        d, mlp = self.cfg.dim, self.cfg.mlp
+        rows_max = max(3 * d, mlp)
+        cap = rows_max * (max(d, mlp) + 128)
+        buf = torch.empty(cap, dtype=torch.uint8)
+        scale = torch.empty(rows_max, dtype=torch.float32)
+        rows, cols, ld = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self.lib.ivit_debug_weight_fp8(self._h, layer, which, ctypes.c_void_p(buf.data_ptr()), cap,
+                                                   ctypes.cast(scale.data_ptr(), ctypes.POINTER(ctypes.c_float)), rows_max,
+                                                   ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(ld)))
+        w = buf[:rows.value * ld.value].reshape(rows.value, ld.value)[:, :cols.value].contiguous().view(torch.float8_e4m3fn)
+        return w, scale[:rows.value].clone()
+
     def debug_unfold(self, x: torch.Tensor, normalise: bool) -> torch.Tensor:
         """bf16 unfold image the patch GEMM consumes, as f32 [B*Np, K] (parity-test inspection)."""
         batch, _ = self._split_batch(x, 0)
@@ -337,4 +400,16 @@ class Engine:
             self._check(self.lib.ivit_profile_read(self._h, c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
             res[self.lib.ivit_profile_class_name(c).decode()] = {
                 "ms": ms.value, "launches": int(n.value), "flops": fl.value, "bytes": by.value}
+        return res
+
+    def profile_kernels(self) -> Dict[str, Dict[str, float]]:
+        """Per launch site ("role:kernel name") totals since profile_reset: which kernel every GEMM of the
+        forward was dispatched to, with its event time and algorithmic FLOPs / bytes."""
+        res = {}
+        name = ctypes.create_string_buffer(160)
+        for i in range(self.lib.ivit_profile_kernel_count(self._h)):
+            ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            self._check(self.lib.ivit_profile_kernel_read(self._h, i, name, len(name), ctypes.byref(ms), ctypes.byref(n),
+                                                          ctypes.byref(fl), ctypes.byref(by)))
+            res[name.value.decode()] = {"ms": ms.value, "launches": int(n.value), "flops": fl.value, "bytes": by.value}
         return res

@@ -144,13 +144,21 @@ def make_vit_model_class(ModelBase, PinoutCls):
 class HipBackend:
     """The product backend: owns an ``Engine`` on one GPU.  Raises if the GPU path is unavailable."""
 
-    def __init__(self, cfg: VitConfig, state_dict: Dict[str, torch.Tensor], device: int = 0, max_batch: int = 1):
+    def __init__(self, cfg: VitConfig, state_dict: Dict[str, torch.Tensor], device: int = 0, max_batch: int = 1,
+                 precision: str = "bf16", check_ln_fold: bool = True):
         from ..engine import Engine  # raises when libivit.so is missing
+        from ..weights import synthetic_images
         if not torch.cuda.is_available():
             raise RuntimeError("no MI355X visible (torch.cuda.is_available() is False); the ViT nodes have no CPU path")
         self.cfg = cfg
         self._module = VitParameters(state_dict)
-        self.engine = Engine(cfg, state_dict, device=device, max_batch=max_batch)
+        self.engine = Engine(cfg, state_dict, device=device, max_batch=max_batch, precision=precision)
+        # A plugin takes whatever checkpoint it is given (reference static/models/vgg16.py:12-14).  The LayerNorm fold
+        # of the engine is only as accurate as the unfolded form while |mean| / std of the residual-stream rows is
+        # small, a property of the weights: measure it once on sample images and let the engine keep or drop the fold.
+        self.ln_fold_ratio = None
+        if check_ln_fold and precision != "fp8" and self.engine.ln_fold:
+            self.ln_fold_ratio = self.engine.calibrate_ln_fold(synthetic_images(min(2, max_batch), cfg, seed=7))
 
     def module(self) -> torch.nn.Module:
         return self._module

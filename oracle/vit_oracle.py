@@ -94,16 +94,24 @@ def token_row(batch_index: int, token: int, tokens: int) -> int:
 # ----------------------------------------------------------------------------------------------
 # floating-point nodes
 # ----------------------------------------------------------------------------------------------
-def rnd(t: torch.Tensor, emulate: bool) -> torch.Tensor:
-    """bf16 round-to-nearest-even of an activation at an engine rounding point (emulate mode)."""
-    return t.to(torch.bfloat16).to(t.dtype) if emulate else t
+# The 16-bit type of the engine's GEMM operand data path that the rounding-aware mode mirrors: bfloat16
+# (IVIT_PRECISION_BF16, the default and the BASELINE headline) or float16 (IVIT_PRECISION_F16: same MFMA rate on
+# gfx950, 11 significant bits instead of 8 - the mode that meets north_star's 1e-3 against the PLAIN f32 forward).
+# Tests / bench set it from Engine.operand_dtype; the plain (emulate=False) forward never looks at it.
+OPERAND_DTYPE = torch.bfloat16
+
+
+def rnd(t: torch.Tensor, emulate: bool, dtype=None) -> torch.Tensor:
+    """Round-to-nearest-even of an activation to the engine's 16-bit operand type at an engine rounding point
+    (emulate mode); ``dtype`` pins the type where the engine's own policy does (bf16 q|k|v on the fp8 path)."""
+    return t.to(torch.float32).to(dtype or OPERAND_DTYPE).to(t.dtype) if emulate else t
 
 
 def _w(sd: Dict[str, torch.Tensor], key: str, dtype, emulate: bool = False) -> torch.Tensor:
-    """A parameter in the compute dtype; ``emulate`` rounds it to bf16 first (weight MATRICES only)."""
+    """A parameter in the compute dtype; ``emulate`` rounds it to the operand type first (weight MATRICES only)."""
     w = sd[key]
     if emulate:
-        w = w.to(torch.float32).to(torch.bfloat16)
+        w = w.to(torch.float32).to(OPERAND_DTYPE)
     return w.to(dtype)
 
 
@@ -162,12 +170,13 @@ def gelu_erf(x: torch.Tensor) -> torch.Tensor:
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False, emulate: bool = False):
-    dt = h.dtype
-    pre = layer_prefix(i) + "self_attention."
-    b, n, d = h.shape
+def attention_core(qkv: torch.Tensor, cfg, emulate: bool = False, p_dtype=None):
+    """Scaled-dot-product attention on a stored q|k|v tensor [B,N,3D] -> (output [B,N,D] before any rounding,
+    probabilities [B,H,N,N]).  emulate: the engine's evaluation - numerators e = exp(s - max) in f32/f64, row sum
+    of the UNROUNDED e, P.V on the 16-bit copy of e (``p_dtype`` pins that type where the engine's policy does)."""
+    b, n, d3 = qkv.shape
+    d = d3 // 3
     hd = cfg.head_dim
-    qkv = rnd(h @ _w(sd, pre + "in_proj_weight", dt, emulate).t() + _w(sd, pre + "in_proj_bias", dt), emulate)
     q, k, v = qkv.split(d, dim=-1)
 
     def heads(t):
@@ -176,14 +185,21 @@ def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False, emul
     q, k, v = heads(q), heads(k), heads(v)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
     if emulate:
-        # engine: numerators e = exp(s - max) in f32, row sum of the UNROUNDED e, P.V on bf16(e)
         e = torch.exp(s - s.amax(dim=-1, keepdim=True))
         p = e / e.sum(dim=-1, keepdim=True)
-        a = (rnd(e, True) @ v) / e.sum(dim=-1, keepdim=True)
+        a = (rnd(e, True, p_dtype) @ v) / e.sum(dim=-1, keepdim=True)
     else:
         p = torch.softmax(s, dim=-1)
         a = p @ v
-    a = rnd(a.transpose(1, 2).reshape(b, n, d), emulate)
+    return a.transpose(1, 2).reshape(b, n, d), p
+
+
+def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False, emulate: bool = False):
+    dt = h.dtype
+    pre = layer_prefix(i) + "self_attention."
+    qkv = rnd(h @ _w(sd, pre + "in_proj_weight", dt, emulate).t() + _w(sd, pre + "in_proj_bias", dt), emulate)
+    a, p = attention_core(qkv, cfg, emulate)
+    a = rnd(a, emulate)
     out = a @ _w(sd, pre + "out_proj.weight", dt, emulate).t() + _w(sd, pre + "out_proj.bias", dt)
     return (out, p) if return_probs else out
 
@@ -208,13 +224,13 @@ LN_FOLD = False
 def folded_linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     """LayerNorm(x) @ w.T + b as the engine's folded GEMM evaluates it (x: [..., D] in the compute dtype)."""
     dt = x.dtype
-    wb = w.to(torch.float32).to(torch.bfloat16).to(dt)                       # the engine's bf16 copy of W
-    wf = (wb * gamma.to(dt)[None, :]).to(torch.float32).to(torch.bfloat16).to(dt)   # W . diag(gamma), rounded again
+    wb = w.to(torch.float32).to(OPERAND_DTYPE).to(dt)                       # the engine's 16-bit copy of W
+    wf = (wb * gamma.to(dt)[None, :]).to(torch.float32).to(OPERAND_DTYPE).to(dt)   # W . diag(gamma), rounded again
     s = wf.sum(dim=1)
     c = wb @ beta.to(dt) + b.to(dt)
     mu = x.mean(dim=-1, keepdim=True)
     rstd = 1.0 / torch.sqrt(((x - mu) ** 2).mean(dim=-1, keepdim=True) + eps)
-    xb = x.to(torch.float32).to(torch.bfloat16).to(dt)
+    xb = x.to(torch.float32).to(OPERAND_DTYPE).to(dt)
     return rstd * (xb @ wf.t() - mu * s) + c
 
 
@@ -277,11 +293,11 @@ def encoder_layer_fp8(x: torch.Tensor, sd, i: int, cfg, scales4) -> torch.Tensor
     b, n, d = x.shape
     hd = cfg.head_dim
     h = q8_act(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), s_h1)
-    qkv = rnd(h @ q8_weight(sd, pre + "self_attention.in_proj_weight", dt).t() + _w(sd, pre + "self_attention.in_proj_bias", dt), True)
+    qkv = rnd(h @ q8_weight(sd, pre + "self_attention.in_proj_weight", dt).t() + _w(sd, pre + "self_attention.in_proj_bias", dt), True, torch.bfloat16)
     q, k, v = [t.reshape(b, n, cfg.heads, hd).transpose(1, 2) for t in qkv.split(d, dim=-1)]
     sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
     e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
-    a = (rnd(e, True) @ v) / e.sum(dim=-1, keepdim=True)
+    a = (rnd(e, True, torch.bfloat16) @ v) / e.sum(dim=-1, keepdim=True)
     a = q8_act(a.transpose(1, 2).reshape(b, n, d), s_att)
     x = x + a @ q8_weight(sd, pre + "self_attention.out_proj.weight", dt).t() + _w(sd, pre + "self_attention.out_proj.bias", dt)
     h = q8_act(layer_norm(x, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps), s_h2)

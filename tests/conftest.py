@@ -25,6 +25,9 @@ def oracle_mirrors_engine_rounding_points():
     folded into the next GEMM (the bf16 default, IVIT_FOLD_LN unset or 1) or a LayerNorm kernel (IVIT_FOLD_LN=0).
     Engine.ln_fold reports what an engine actually does; the GPU tests assert that it agrees with this."""
     from oracle import vit_oracle
+    import torch
     vit_oracle.LN_FOLD = os.environ.get("IVIT_FOLD_LN", "1") != "0"
+    vit_oracle.OPERAND_DTYPE = torch.bfloat16
     yield
     vit_oracle.LN_FOLD = False
+    vit_oracle.OPERAND_DTYPE = torch.bfloat16

@@ -75,3 +75,23 @@ def test_two_rank_gloo_all_gather_reassembles_the_batch(total):
         assert logits.shape == (total, cfg.classes) and cls.shape == (total, cfg.dim)
         assert torch.allclose(logits, full["logits"], atol=1e-5)     # every rank holds the whole batch
         assert torch.allclose(cls, full["cls"], atol=1e-5)
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus N` must work un-wrapped (the driver's plain invocation): before touching the GPU it
+    starts torch.distributed.run as a CHILD and relays the result line.  Without a GPU every rank stops with the
+    engine's loud "no GPU" message - what matters here is that N ranks were started and that their failure is
+    reported through the parent's exit code (no re-exec, no silent fallback)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by tests/test_gpu_distributed.py")
+    assert r.returncode != 0
+    assert r.stderr.count("no GPU visible") >= 2, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

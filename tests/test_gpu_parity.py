@@ -21,8 +21,15 @@ from interactive_vit_amd.weights import init_weights, synthetic_images
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-3          # the tolerance north_star states for bf16 (vs the rounding-aware oracle)
-BF16_VS_F32_NODE = 5e-3  # one node vs the plain f32 oracle: bf16 rounding of both GEMM operands
-BF16_VS_F32_E2E = 2e-2   # whole forward vs the plain f32 oracle (rounding noise of 2+4L GEMMs)
+# Against the PLAIN f32 forward the distance is the bf16 operand rounding itself.  Bounds = measured on MI355X + 25 %
+# (a 3x allowance hides regressions): one node 2.2e-3...2.8e-3 -> 3.5e-3; whole chains per model below.
+BF16_VS_F32_NODE = 3.5e-3
+E2E_MEASURED = {"vit_test": 4.1e-3, "vit_test80": 3.0e-3, "vit_ti_16": 4.0e-3, "vit_b_16": 9.3e-3, "vit_l_16_384": 4.0e-3, "vit_h_14": 1.0e-2}   # max over the tests' seeds
+
+
+def e2e_bound(cfg) -> float:
+    """Whole-chain bound vs the plain f32 oracle for a model: measured + 25 %."""
+    return 1.25 * E2E_MEASURED[cfg.name]
 
 
 def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
@@ -141,11 +148,11 @@ def test_fused_forward_matches_chain_and_oracle(small):
     # whole-chain comparisons sit at the bf16 rounding floor against EITHER oracle: a difference d
     # in front of a rounding to a grid of spacing u comes out as ~sqrt(d*u), so chained roundings
     # decorrelate the two computations up to the rounding noise itself (per-node gate: test above)
-    assert rel_err(logits, emu["logits"]) <= BF16_VS_F32_E2E
-    assert rel_err(logits, ref["logits"]) <= BF16_VS_F32_E2E
+    assert rel_err(logits, emu["logits"]) <= e2e_bound(cfg)
+    assert rel_err(logits, ref["logits"]) <= e2e_bound(cfg)
     # class-token features after encoder.ln feed `heads`; cls_out is the [B,D] f32 row of it
-    assert rel_err(cls, emu["cls"]) <= BF16_VS_F32_E2E
-    assert rel_err(cls, ref["cls"]) <= BF16_VS_F32_E2E
+    assert rel_err(cls, emu["cls"]) <= e2e_bound(cfg)
+    assert rel_err(cls, ref["cls"]) <= e2e_bound(cfg)
     # node-by-node on the GPU gives the SAME bits as the fused range (same kernels, same order)
     cur = x.cuda()
     for suffix in vit_oracle.node_suffixes(cfg):
@@ -175,6 +182,25 @@ def test_errors_are_exceptions_with_messages(small):
         eng.forward(torch.zeros(cfg.patches, cfg.dim), 2, 2)
 
 
+def test_engine_on_an_absent_device_is_refused_with_a_message(small):
+    """ivit_config.device selects the GPU; kernel attributes are kept per (device, kernel) inside the library
+    (csrc/kernels_gemm.hip: ensure_dynamic_lds), and a device this process cannot see is an error, not device 0."""
+    from interactive_vit_amd.engine import Engine, EngineError
+    cfg, sd, eng = small
+    n = torch.cuda.device_count()
+    with pytest.raises(EngineError, match="not present"):
+        Engine(cfg, sd, device=n, max_batch=1)
+    # engines created and destroyed repeatedly on the same device keep working (the attribute cache is per device, not per engine)
+    x = synthetic_images(1, cfg, seed=3).cuda()
+    ref = eng.forward(x, 0, len(eng.stages))
+    for _ in range(2):
+        e2 = Engine(cfg, sd, device=0, max_batch=1)
+        try:
+            assert torch.equal(e2.forward(x, 0, len(e2.stages)), ref)
+        finally:
+            e2.close()
+
+
 def test_vit_tiny_forward():
     """BASELINE config 1 model (ViT-Ti/16, 197 tokens) on one image and a ragged batch."""
     from interactive_vit_amd.engine import Engine
@@ -189,10 +215,10 @@ def test_vit_tiny_forward():
         logits = eng.forward(x.cuda(), 0, len(eng.stages)).cpu()
         e_emu, e_f32 = rel_err(logits, emu["logits"]), rel_err(logits, acts["logits"])
         print(f"vit_ti_16 logits (whole chain): vs rounding-aware oracle {e_emu:.2e}, vs plain f32 {e_f32:.2e}")
-        assert e_emu <= BF16_VS_F32_E2E
-        assert e_f32 <= BF16_VS_F32_E2E
+        assert e_emu <= e2e_bound(cfg)
+        assert e_f32 <= e2e_bound(cfg)
         mid = eng.forward(x.cuda(), 0, 3 + 6).cpu()          # after encoder layer 5
-        assert rel_err(mid, acts["encoder.layers.5"]) <= BF16_VS_F32_E2E
+        assert rel_err(mid, acts["encoder.layers.5"]) <= e2e_bound(cfg)
         strict_nodes(eng, cfg, sd, acts, x, ["conv_proj", "encoder.layers.0", "encoder.layers.11", "heads"])
     finally:
         eng.close()
@@ -217,8 +243,8 @@ def test_vit_b16_batch_parity_and_properties():
         emu = vit_oracle.forward(x[:2].double(), sd, cfg, emulate=True)
         e_emu, e_f32 = rel_err(logits[:2], emu["logits"]), rel_err(logits[:2], ref["logits"])
         print(f"vit_b_16 logits (whole chain): vs rounding-aware oracle {e_emu:.2e}, vs plain f32 {e_f32:.2e}")
-        assert e_emu <= BF16_VS_F32_E2E
-        assert e_f32 <= BF16_VS_F32_E2E
+        assert e_emu <= e2e_bound(cfg)
+        assert e_f32 <= e2e_bound(cfg)
         acts = vit_oracle.forward(x[:2], sd, cfg, keep=True)
         strict_nodes(eng, cfg, sd, acts, x[:2], ["conv_proj", "encoder.layers.0", "encoder.layers.7", "heads"])
         # 24 images = 4728 token rows: the QKV projection now takes the staggered 256x256 GEMM tile
@@ -261,7 +287,7 @@ def test_vit_l16_384_long_sequence():
         # first layers of the chain stay inside the bf16 whole-chain bound
         mid_ref = vit_oracle.encoder_layer(vit_oracle.encoder_layer(tok, sd, 0, cfg), sd, 1, cfg)
         mid = eng.forward(x1.cuda(), 0, 5).cpu()
-        assert rel_err(mid, mid_ref) <= BF16_VS_F32_E2E
+        assert rel_err(mid, mid_ref) <= e2e_bound(cfg)
     finally:
         eng.close()
 
@@ -443,7 +469,7 @@ def test_head_dim_80_and_patch_14_small():
         acts = vit_oracle.forward(x, sd, cfg, keep=True)
         strict_nodes(eng, cfg, sd, acts, x, vit_oracle.node_suffixes(cfg))
         logits = eng.forward(x.cuda(), 0, len(eng.stages))
-        assert rel_err(logits, acts["logits"]) <= BF16_VS_F32_E2E
+        assert rel_err(logits, acts["logits"]) <= e2e_bound(cfg)
         amap = eng.run_node("encoder.layers.1.attn", acts["encoder.layers.0"].cuda()).cpu()
         emu = vit_oracle.attention_map(acts["encoder.layers.0"].double(), sd, 1, cfg, emulate=True)
         assert rel_err(amap, emu) <= REL_TOL
@@ -475,7 +501,7 @@ def test_vit_h14_bf16_shapes():
         # ViT-H, measured.  GEMM-only nodes stay at 4e-7.  Bar for this config: 2e-3.
         strict_nodes(eng, cfg, sd, acts, x1, ["encoder.layers.0"], tol=2e-3)
         ref = vit_oracle.forward(x1, sd, cfg)["logits"]
-        assert rel_err(logits[:1], ref) <= BF16_VS_F32_E2E
+        assert rel_err(logits[:1], ref) <= e2e_bound(cfg)
     finally:
         eng.close()
 

@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
+#include <map>
 #include <vector>
 using namespace ivit;
 
@@ -75,6 +77,21 @@ int main(int argc, char** argv) {
     float2* dpart; bf16_t* dxb;
     CK(hipMalloc(&dpart, (size_t)maxM * GEMM_LN_SLOTS * 8)); CK(hipMalloc(&dxb, (size_t)maxM * maxN * 2));
 
+    // ablation configurations "unused:order[,...]" (IVIT_CFGS); the first one is the baseline.  (The first field was a start
+    // delay for the second workgroup of a CU: measured in round 2, no gain - co-resident workgroups de-synchronise by themselves.)
+    struct Cfg { int stagger, order; };
+    std::vector<Cfg> cfgs;
+    {
+        const char* cs = getenv("IVIT_CFGS");
+        std::string str = cs ? cs : "0:0";
+        size_t pos = 0;
+        while (pos < str.size()) {
+            size_t end = str.find(',', pos); if (end == std::string::npos) end = str.size();
+            int a = 0, b = 0; sscanf(str.substr(pos, end - pos).c_str(), "%d:%d", &a, &b);
+            cfgs.push_back({a, b}); pos = end + 1;
+        }
+    }
+
     int shape_idx = -1;
     for (const Shape& s : shapes) {
         ++shape_idx;
@@ -128,20 +145,87 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        std::vector<std::vector<double>> ctimes(cfgs.size() * GEMM_VARIANTS);
         for (int round = 0; round < rounds; ++round)
+            for (size_t ci = 0; ci < cfgs.size(); ++ci)
             for (int v = 0; v < GEMM_VARIANTS; ++v) {
                 if (!((vmask >> v) & 1)) continue;
                 if (s.epi >= EPI_BIAS_RESID_STATS && v != GEMM_TILE_128 && v != GEMM_TILE_160 && v != GEMM_TILE_256S) continue;
+                if (ci > 0 && v != GEMM_TILE_128 && v != GEMM_TILE_160) continue;   // the ablation knobs live in gemm_body
+                GemmParams q = p; q.order = cfgs[ci].order;
                 const int iters = rounds >= 7 ? 10 : 2;
-                CK(launch_gemm_variant(p, v, 0));
+                CK(launch_gemm_variant(q, v, 0));
                 CK(hipEventRecord(e0, 0));
-                for (int i = 0; i < iters; ++i) CK(launch_gemm_variant(p, v, 0));
+                for (int i = 0; i < iters; ++i) CK(launch_gemm_variant(q, v, 0));
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-                times[v].push_back(ms / iters);
+                if (ci == 0) times[v].push_back(ms / iters);
+                ctimes[ci * GEMM_VARIANTS + v].push_back(ms / iters);
             }
-        if (stamp_variant >= 0) {
+        for (size_t ci = 1; ci < cfgs.size(); ++ci)
+            for (int v = 0; v < GEMM_VARIANTS; ++v) {
+                auto& tv = ctimes[ci * GEMM_VARIANTS + v];
+                if (tv.empty()) continue;
+                std::sort(tv.begin(), tv.end());
+                const double fl = 2.0 * s.M * s.N * s.K, med = tv[tv.size() / 2];
+                printf("   %-28s stagger %4d order %d: median %8.2f us  %7.1f TF/s   (min %8.2f us)\n", gemm_variant_name(v), cfgs[ci].stagger, cfgs[ci].order, med * 1e3, fl / med / 1e9, tv[0] * 1e3);
+            }
+        if (stamp_variant == GEMM_TILE_128 || stamp_variant == GEMM_TILE_160) {   // gemm_body: per-CU timelines (who overlaps whom)
+          for (size_t ci = 0; ci < cfgs.size(); ++ci) {
+            CK(hipMemset(dstamps, 0, (size_t)max_blocks * 16 * 8));
+            GemmParams q = p; q.stamps = dstamps; q.order = cfgs[ci].order;
+            GemmParams qw = q; qw.stamps = nullptr;
+            for (int i = 0; i < 3; ++i) CK(launch_gemm_variant(qw, stamp_variant, 0));
+            CK(hipDeviceSynchronize());
+            CK(launch_gemm_variant(q, stamp_variant, 0));
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> hs((size_t)max_blocks * 16);
+            CK(hipMemcpy(hs.data(), dstamps, hs.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long tmin = ~0ull, tmax = 0; int nb = 0;
+            for (int b = 0; b < max_blocks; ++b) if (hs[(size_t)b * 16]) { tmin = std::min(tmin, hs[(size_t)b * 16]); tmax = std::max(tmax, hs[(size_t)b * 16 + 4]); nb = b + 1; }
+            std::map<unsigned long long, std::vector<int>> by_cu;
+            double seg[5] = {0, 0, 0, 0, 0}; int cnt = 0;
+            for (int b = 0; b < nb; ++b) {
+                const unsigned long long* t = &hs[(size_t)b * 16];
+                if (!t[0]) continue;
+                ++cnt;
+                for (int k = 1; k < 5; ++k) seg[k] += (double)(t[k] - t[k - 1]) * 0.01;
+                by_cu[t[5] & 0xf0000ff00ull].push_back(b);
+            }
+            // per CU: how much of every block's epilogue [t2, t4] lies inside another block's K loop [t1, t2] on the same CU
+            double epi_total = 0, epi_covered = 0, k_total = 0, k_shared = 0;
+            size_t max_res = 0;
+            for (auto& kv : by_cu) {
+                max_res = std::max(max_res, kv.second.size());
+                for (int a : kv.second) {
+                    const unsigned long long* ta = &hs[(size_t)a * 16];
+                    epi_total += (double)(ta[4] - ta[2]);
+                    k_total += (double)(ta[2] - ta[1]);
+                    for (int b : kv.second) {
+                        if (a == b) continue;
+                        const unsigned long long* tb = &hs[(size_t)b * 16];
+                        const long long lo = (long long)std::max(ta[2], tb[1]), hi = (long long)std::min(ta[4], tb[2]);
+                        if (hi > lo) epi_covered += (double)(hi - lo);
+                        const long long lo2 = (long long)std::max(ta[1], tb[1]), hi2 = (long long)std::min(ta[2], tb[2]);
+                        if (hi2 > lo2) k_shared += (double)(hi2 - lo2);
+                    }
+                }
+            }
+            printf("   stamps %s stagger %d order %d: %d blocks on %zu CUs (max %zu per CU); kernel span %.2f us\n", gemm_variant_name(stamp_variant), cfgs[ci].stagger, cfgs[ci].order,
+                   cnt, by_cu.size(), max_res, (double)(tmax - tmin) * 0.01);
+            printf("      per block: start->K loop %.2f us | K loop %.2f us | epilogue issue %.2f us | store drain %.2f us\n", seg[1] / cnt, seg[2] / cnt, seg[3] / cnt, seg[4] / cnt);
+            printf("      epilogue time inside another workgroup's K loop on the same CU: %.1f %%; K-loop time shared with another K loop: %.1f %%\n",
+                   100.0 * epi_covered / epi_total, 100.0 * k_shared / k_total);
+            // one CU's timeline
+            const auto& one = by_cu.begin()->second;
+            for (int b : one) {
+                const unsigned long long* t = &hs[(size_t)b * 16];
+                printf("      cu %llx block %4d slot %llu: start %7.2f  kloop %7.2f  epi %7.2f  end %7.2f\n", (unsigned long long)(t[5] & 0xf0000ff00ull), b, (t[5] >> 40) & 0xff,
+                       (double)(t[0] - tmin) * 0.01, (double)(t[1] - tmin) * 0.01, (double)(t[2] - tmin) * 0.01, (double)(t[4] - tmin) * 0.01);
+            }
+          }
+        } else if (stamp_variant >= 0) {
             CK(hipMemset(dstamps, 0, (size_t)max_blocks * 16 * 8));
             GemmParams q = p; q.stamps = dstamps;
             for (int i = 0; i < 3; ++i) CK(launch_gemm_variant(p, stamp_variant, 0));   // warm
