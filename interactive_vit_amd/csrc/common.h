@@ -38,6 +38,15 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, r);
 }
 
+// two f32 -> packed IEEE f16x2 in one dword, round to nearest even (IVIT_PRECISION_F16 data path)
+__device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    f2 v = {lo, hi};
+    h2 r = __builtin_convertvector(v, h2);
+    return __builtin_bit_cast(unsigned int, r);
+}
+
 // fp8 (OCP e4m3fn on gfx950): two f32 -> two fp8 bytes, round to nearest even, SATURATING at +-448
 // (clamped here in software: torch's cast gives NaN above 448 and the oracle clamps the same way).
 constexpr float FP8_MAX = 448.0f;

@@ -47,7 +47,10 @@ struct GemmParams {
     int order;                      // microbenchmark builds only: 1 = row bands per XCD (tile_coords_banded)
 };
 
-enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_VARIANTS = 8 };
+enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_TILE_PE = 8, GEMM_VARIANTS = 9 };
+// GEMM_TILE_PE (gemmpe_kernel.h: persistent 256 x 128, epilogue interleaved into the next tile's main loop) serves the 16-bit-output
+// epilogues only; gemm_pe_supported says whether a call can take it (shape limits, LayerNorm operands as per-slot pairs)
+bool gemm_pe_supported(const GemmParams& p);
 // fp8 (e4m3) operands, f32 accumulate: A [M,K] and W [N,K] are BYTE matrices (lda/ldw in elements = bytes)
 hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream);
 // Operand allocations must be readable up to the tile edge: A rows up to round_up(M,256)+256,

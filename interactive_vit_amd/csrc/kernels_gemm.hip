@@ -1,17 +1,21 @@
 // Instantiations of the bf16 MFMA GEMM template (gemm_kernel.h) and the per-shape tile choice.
 #include "gemm256s_kernel.h"
+#include "gemmpe_kernel.h"
 #ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost (csrc/study/)
 #include "study/gemm256p_kernel.h"
 #include "study/gemm256ps_kernel.h"
 #include "study/gemm160x256_kernel.h"
 #include "study/gemm160x256w4_kernel.h"
 #endif
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 #include <set>
 #include <utility>
 
 namespace ivit {
+
+static int device_cu_count();
 
 using Tile128 = GemmTile<2, 2, 4, 4>;   // 128 x 128, 4 waves (64x64 each), 64 KiB LDS, 2 blocks/CU
 using Tile160 = GemmTile<2, 2, 5, 4>;   // 160 x 128, 4 waves (80x64 each), 72 KiB LDS, 2 blocks/CU
@@ -45,6 +49,16 @@ __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x6
 __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag_lf(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm256s_body<0, false, 2>(p, smem);
+}
+
+// persistent 256 x 128 tile with the previous tile's epilogue interleaved into the main loop (gemmpe_kernel.h)
+__global__ __launch_bounds__(TilePE::THREADS, 2) void ivit_gemm_bf16_256x128x64_pe(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemmpe_body<OpBf16, false>(p, smem);
+}
+__global__ __launch_bounds__(TilePE::THREADS, 2) void ivit_gemm_bf16_256x128x64_pe_gelu(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemmpe_body<OpBf16, true>(p, smem);
 }
 
 // fp8 (e4m3) operands: same tiles, K-tile of 128 elements, two fp8 MFMA steps per 16-B fragment
@@ -113,6 +127,7 @@ const char* gemm_variant_name(int v) {
         case GEMM_TILE_160X256: return "ivit_gemm_bf16_160x256x64";
         case GEMM_TILE_160X256W4: return "ivit_gemm_bf16_160x256x64_w4";
         case GEMM_TILE_256PS: return "ivit_gemm_bf16_256x256x64_persist";
+        case GEMM_TILE_PE: return "ivit_gemm_bf16_256x128x64_pe";
     }
     return "?";
 }
@@ -179,11 +194,6 @@ int gemm_pick_variant(int M, int N, int K) {
     return best;
 }
 
-static int device_cu_count() {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus;
-}
 
 #ifdef IVIT_GEMM_ABLATIONS
 // persistent kernel: one workgroup per CU (or per tile when there are fewer tiles than CUs)
@@ -198,11 +208,46 @@ static hipError_t launch_persistent(const GemmParams& p, hipStream_t stream) {
 }
 #endif
 
+static int device_cu_count() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+}
+
+bool gemm_pe_supported(const GemmParams& p) {
+    const bool fold = p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16;
+    if (!fold && p.epi != EPI_BIAS_BF16 && p.epi != EPI_BIAS_GELU_BF16) return false;
+    if (p.N % TilePE::BN || p.K % GEMM_BK || p.colscale || p.grp_in || !p.ln_s || (p.ldo % 8)) return false;
+    const int nt = p.K / GEMM_BK;
+    if (nt < TilePE::MIN_KT) return false;
+    if (fold) {   // statistics arrive as per-slot pairs and the fold pipeline (an even number of 4-slot chunks) fits a tile
+        if (!p.ln_part || p.ln_stats || p.ln_dim <= 0 || p.ln_dim > 64 * GEMM_LN_SLOTS) return false;
+        const int nchunks = (((p.ln_dim + 63) >> 6) + 3) >> 2;
+        if (std::max(2, (nchunks + 1) & ~1) > nt - 6) return false;
+    }
+    return true;
+}
+
+static hipError_t launch_pe(const GemmParams& p, hipStream_t stream) {
+    if (!gemm_pe_supported(p)) return hipErrorInvalidValue;
+    const bool gelu = p.epi == EPI_BIAS_GELU_BF16 || p.epi == EPI_LNFOLD_GELU_BF16;
+    GemmParams q = p;
+    if (p.epi == EPI_BIAS_BF16 || p.epi == EPI_BIAS_GELU_BF16) { q.ln_part = nullptr; q.ln_stats = nullptr; q.ln_dim = 0; }   // ln_s must be a zero vector
+    auto kernel = gelu ? ivit_gemm_bf16_256x128x64_pe_gelu : ivit_gemm_bf16_256x128x64_pe;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), TilePE::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int tiles = ceil_div(p.M, TilePE::BM) * (p.N / TilePE::BN);
+    const int grid = std::min(tiles, device_cu_count());
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(TilePE::THREADS), TilePE::LDS_BYTES, stream, q);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (p.K <= 0 || p.K % GEMM_BK != 0) return hipErrorInvalidValue;
     if ((p.lda % 8) || (p.ldw % 8)) return hipErrorInvalidValue;   // 16-B aligned rows for the DMA
     if ((p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
+    if (variant == GEMM_TILE_PE) return launch_pe(p, stream);
     const int family = p.epi == EPI_BIAS_RESID_STATS ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
     if (family) {   // LayerNorm-fold epilogues: their own instantiations of the three product tiles
         if (p.grp_in != 0) return hipErrorInvalidValue;

@@ -37,10 +37,15 @@ def rel_err(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-def check_stored(name, got, ref, mant_bits, tiny):
-    """got / ref: the same storage type, as float64.  One-unit-in-the-last-place closeness + identical fraction."""
+def check_stored(name, got, ref, mant_bits, tiny, floor=1e-3):
+    """got / ref: the same storage type, as float64.  One-unit-in-the-last-place closeness + identical fraction.
+    Elements smaller than `floor` x the tensor's maximum are held to the unit of that magnitude.  1e-3 for a bf16 / f16
+    GEMM (f32 accumulation error of a sum that cancels); 1e-2 for the fp8 GEMMs (the 128-deep scaled MFMA rounds its
+    partial sums more coarsely: 1 % of outputs sit on the other side of a rounding boundary, against 0.01 %); 5e-2 for
+    attention, where a single flipped rounding of a dominant softmax numerator moves an output that is a cancelling
+    average of +- values by 2^-9 |p v|, i.e. by several units of its own small size."""
     got = got.double().cpu(); ref = ref.double().cpu()
-    scale = torch.maximum(got.abs(), ref.abs()).clamp_min(1e-3 * float(ref.abs().max()))
+    scale = torch.maximum(got.abs(), ref.abs()).clamp_min(floor * float(ref.abs().max()))
     ulp = torch.maximum(2.0 ** (torch.floor(torch.log2(scale.clamp_min(1e-300))) - mant_bits), torch.full_like(scale, tiny))
     worst = float(((got - ref).abs() / ulp).max())
     same = float((got == ref).double().mean())
@@ -122,7 +127,7 @@ def per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales4=None):
     if fp8:
         w8, rs = q8(0)
         ref = (h1.to(torch.float32).to(f64) @ w8.t()) * (s_h1 * rs).double()[None, :] + vec("self_attention.in_proj_bias")
-        check_stored("qkv (fp8 GEMM -> bf16)", tap["qkv"], ref.to(torch.float32).to(torch.bfloat16), *storage(torch.bfloat16))
+        check_stored("qkv (fp8 GEMM -> bf16)", tap["qkv"], ref.to(torch.float32).to(torch.bfloat16), *storage(torch.bfloat16), floor=1e-2)
     elif fold:
         ref = folded(x0, h1.to(f64), "self_attention.in_proj_weight", "self_attention.in_proj_bias", "ln_1.weight", "ln_1.bias")
         check_stored("qkv (LN-fold GEMM)", tap["qkv"], ref.to(torch.float32).to(op), mb16, tiny16)
@@ -134,9 +139,9 @@ def per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales4=None):
     a, _ = vo.attention_core(qkv, cfg, emulate=True, p_dtype=torch.bfloat16 if fp8 else op)
     a = a.reshape(-1, d)
     if fp8:
-        check_stored("att (-> e4m3)", tap["att"].to(torch.float32), quant(a, s_att).to(torch.float32), *storage(torch.float8_e4m3fn))
+        check_stored("att (-> e4m3)", tap["att"].to(torch.float32), quant(a, s_att).to(torch.float32), *storage(torch.float8_e4m3fn), floor=5e-2)
     else:
-        check_stored("att", tap["att"], a.to(torch.float32).to(op), mb16, tiny16)
+        check_stored("att", tap["att"], a.to(torch.float32).to(op), mb16, tiny16, floor=5e-2)
     # ---- step 4: out-projection + residual on the engine's attention output (f32 stream)
     if fp8:
         w8, rs = q8(1)
@@ -159,7 +164,7 @@ def per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales4=None):
     if fp8:
         w8, rs = q8(2)
         pre_act = (h2.to(torch.float32).to(f64) @ w8.t()) * (s_h2 * rs).double()[None, :] + vec("mlp.0.bias")
-        check_stored("u (fp8 GEMM + GELU -> e4m3)", tap["u"].to(torch.float32), quant(vo.gelu_erf(pre_act), s_u).to(torch.float32), *storage(torch.float8_e4m3fn))
+        check_stored("u (fp8 GEMM + GELU -> e4m3)", tap["u"].to(torch.float32), quant(vo.gelu_erf(pre_act), s_u).to(torch.float32), *storage(torch.float8_e4m3fn), floor=1e-2)
     elif fold:
         pre_act = folded(x1, h2.to(f64), "mlp.0.weight", "mlp.0.bias", "ln_2.weight", "ln_2.bias")
         check_stored("u (LN-fold GEMM + GELU)", tap["u"], vo.gelu_erf(pre_act).to(torch.float32).to(op), mb16, tiny16)

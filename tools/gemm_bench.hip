@@ -73,6 +73,7 @@ int main(int argc, char** argv) {
     const int max_blocks = 4096;
     CK(hipMalloc(&dstamps, (size_t)max_blocks * 16 * 8));
 
+    float* dzeros; CK(hipMalloc(&dzeros, maxN * 4)); CK(hipMemset(dzeros, 0, maxN * 4));
     // LayerNorm-fold epilogues: statistics table and bf16 copy
     float2* dpart; bf16_t* dxb;
     CK(hipMalloc(&dpart, (size_t)maxM * GEMM_LN_SLOTS * 8)); CK(hipMalloc(&dxb, (size_t)maxM * maxN * 2));
@@ -100,7 +101,7 @@ int main(int argc, char** argv) {
         p.A = dA; p.lda = s.K; p.W = dW; p.ldw = s.K; p.M = s.M; p.N = s.N; p.K = s.K; p.bias = db; p.epi = s.epi;
         p.out = dout; p.ldo = s.N; p.resid = dres; p.ldr = s.N; p.debug = debug;
         p.ln_part = dpart; p.xb = dxb; p.ldxb = s.N;
-        p.ln_s = db; p.ln_eps = 1e-6f; p.ln_dim = s.K;   // EPI_LNFOLD_*: statistics folded from dpart (timing only; the engine tests check values)
+        p.ln_s = (s.epi == EPI_LNFOLD_BF16 || s.epi == EPI_LNFOLD_GELU_BF16) ? db : dzeros; p.ln_eps = 1e-6f; p.ln_dim = s.K;   // EPI_LNFOLD_*: statistics folded from dpart
         // correctness on sampled rows (epilogue F32 so the values are comparable)
         std::vector<int> rows(NR);
         for (int i = 0; i < NR; ++i) rows[i] = (int)((long long)i * (s.M - 1) / (NR - 1));
@@ -112,6 +113,44 @@ int main(int argc, char** argv) {
         double best[GEMM_VARIANTS]; std::vector<double> times[GEMM_VARIANTS];
         for (int v = 0; v < GEMM_VARIANTS; ++v) {
             if (!((vmask >> v) & 1)) continue;
+            if (v == GEMM_TILE_PE) {   // 16-bit outputs only: bias epilogue against the naive rows, then the shape's own epilogue BITWISE against the 160x128 kernel
+                GemmParams q = p; q.epi = EPI_BIAS_BF16; q.debug = 0; q.ln_s = dzeros; q.ldo = s.N;
+                if (!gemm_pe_supported(q)) { printf("   %-28s not applicable to this shape\n", gemm_variant_name(v)); continue; }
+                bf16_t* o16 = reinterpret_cast<bf16_t*>(dout);
+                CK(hipMemset(dout, 0xff, (size_t)s.M * s.N * 2));
+                CK(launch_gemm_variant(q, v, 0));
+                CK(hipDeviceSynchronize());
+                double maxerr = 0, maxref = 0;
+                std::vector<bf16_t> h16((size_t)s.N);
+                for (int i = 0; i < NR; ++i) {
+                    CK(hipMemcpy(h16.data(), o16 + (size_t)rows[i] * s.N, s.N * 2, hipMemcpyDeviceToHost));
+                    for (int n = 0; n < s.N; ++n) { unsigned u = (unsigned)h16[n] << 16; float f; memcpy(&f, &u, 4); maxerr = std::max(maxerr, (double)fabsf(f - href[(size_t)i * s.N + n])); maxref = std::max(maxref, (double)fabsf(href[(size_t)i * s.N + n])); }
+                }
+                printf("   %-28s check (bf16 out): max err %.3e (max ref %.3f) %s\n", gemm_variant_name(v), maxerr, maxref, maxerr <= 6e-3 * maxref ? "OK" : "MISMATCH");
+                const bool own = s.epi == EPI_BIAS_BF16 || s.epi == EPI_BIAS_GELU_BF16 || s.epi == EPI_LNFOLD_BF16 || s.epi == EPI_LNFOLD_GELU_BF16;
+                if (own && gemm_pe_supported(p)) {
+                    std::vector<bf16_t> ref16((size_t)s.M * s.N), got16((size_t)s.M * s.N);
+                    if (s.epi >= EPI_LNFOLD_BF16) {   // real statistics pairs: leave them with the residual epilogue of the 160x128 kernel on another buffer
+                        GemmParams r = p; r.epi = EPI_BIAS_RESID_STATS; r.N = s.K; r.K = 768; r.out = dres; r.ldo = s.K; r.resid = dres; r.ldr = s.K; r.xb = dxb; r.ldxb = s.K; r.ln_part = dpart;
+                        r.ln_s = nullptr; r.lda = r.K; r.ldw = r.K;
+                        CK(launch_gemm_variant(r, GEMM_TILE_160, 0));
+                        CK(hipDeviceSynchronize());
+                    }
+                    GemmParams a = p; a.debug = 0;
+                    CK(launch_gemm_variant(a, GEMM_TILE_160, 0));
+                    CK(hipDeviceSynchronize());
+                    CK(hipMemcpy(ref16.data(), dout, ref16.size() * 2, hipMemcpyDeviceToHost));
+                    CK(hipMemset(dout, 0xff, (size_t)s.M * s.N * 2));
+                    CK(launch_gemm_variant(a, GEMM_TILE_PE, 0));
+                    CK(hipDeviceSynchronize());
+                    CK(hipMemcpy(got16.data(), dout, got16.size() * 2, hipMemcpyDeviceToHost));
+                    size_t bad = 0, first = 0;
+                    for (size_t i = 0; i < got16.size(); ++i) if (got16[i] != ref16[i]) { if (!bad) first = i; ++bad; }
+                    printf("   %-28s own epilogue vs 160x128: %zu of %zu outputs differ%s", gemm_variant_name(v), bad, got16.size(), bad ? "" : " (bit-identical)\n");
+                    if (bad) printf("; first at row %zu col %zu: %04x vs %04x\n", first / s.N, first % s.N, got16[first], ref16[first]);
+                }
+                continue;
+            }
             GemmParams q = p; q.epi = EPI_BIAS_F32; q.debug = 0;
             CK(hipMemset(dout, 0xff, (size_t)s.M * s.N * 4));
             CK(launch_gemm_variant(q, v, 0));
@@ -150,7 +189,8 @@ int main(int argc, char** argv) {
             for (size_t ci = 0; ci < cfgs.size(); ++ci)
             for (int v = 0; v < GEMM_VARIANTS; ++v) {
                 if (!((vmask >> v) & 1)) continue;
-                if (s.epi >= EPI_BIAS_RESID_STATS && v != GEMM_TILE_128 && v != GEMM_TILE_160 && v != GEMM_TILE_256S) continue;
+                if (s.epi >= EPI_BIAS_RESID_STATS && v != GEMM_TILE_128 && v != GEMM_TILE_160 && v != GEMM_TILE_256S && v != GEMM_TILE_PE) continue;
+                if (v == GEMM_TILE_PE && !gemm_pe_supported(p)) continue;
                 if (ci > 0 && v != GEMM_TILE_128 && v != GEMM_TILE_160) continue;   // the ablation knobs live in gemm_body
                 GemmParams q = p; q.order = cfgs[ci].order;
                 const int iters = rounds >= 7 ? 10 : 2;
@@ -171,7 +211,32 @@ int main(int argc, char** argv) {
                 const double fl = 2.0 * s.M * s.N * s.K, med = tv[tv.size() / 2];
                 printf("   %-28s stagger %4d order %d: median %8.2f us  %7.1f TF/s   (min %8.2f us)\n", gemm_variant_name(v), cfgs[ci].stagger, cfgs[ci].order, med * 1e3, fl / med / 1e9, tv[0] * 1e3);
             }
-        if (stamp_variant == GEMM_TILE_128 || stamp_variant == GEMM_TILE_160) {   // gemm_body: per-CU timelines (who overlaps whom)
+        if (stamp_variant == GEMM_TILE_PE && gemm_pe_supported(p)) {   // shader-clock stamps of one plain K-step (tile 1, K-step nt-2) per workgroup
+            CK(hipMemset(dstamps, 0, (size_t)max_blocks * 16 * 8));
+            GemmParams q = p; q.stamps = dstamps;   // (p.debug = argv[5]: 1 = no DMA in the loop, 2 = no MFMA)
+            for (int i = 0; i < 3; ++i) CK(launch_gemm_variant(p, GEMM_TILE_PE, 0));
+            CK(hipDeviceSynchronize());
+            CK(launch_gemm_variant(q, GEMM_TILE_PE, 0));
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> hs((size_t)256 * 128);
+            CK(hipMemcpy(hs.data(), dstamps, hs.size() * 8, hipMemcpyDeviceToHost));
+            const char* names[9] = {"SR0 reads issue", "barrier 1", "M0 (16 MFMA)", "barrier 2", "SR1 reads + DMA issue", "vmcnt wait", "barrier 3", "M1 (16 MFMA)", "barrier 4"};
+            for (int grp = 0; grp < 2; ++grp) {
+                double seg[9] = {0}; int cnt = 0;
+                for (int b = 0; b < 256; ++b)
+                    for (int w = grp * 4; w < grp * 4 + 4; ++w) {
+                        const unsigned long long* t = &hs[(size_t)b * 128 + w * 16];
+                        if (!t[0] || !t[9]) continue;
+                        ++cnt;
+                        for (int k = 0; k < 9; ++k) seg[k] += (double)(t[k + 1] - t[k]);
+                    }
+                if (!cnt) continue;
+                double tot = 0; for (int k = 0; k < 9; ++k) tot += seg[k] / cnt;
+                printf("   PE K-step stamps, waves %d-%d (%d waves), shader cycles: total %.0f |", grp * 4, grp * 4 + 3, cnt, tot);
+                for (int k = 0; k < 9; ++k) printf(" %s %.0f |", names[k], seg[k] / cnt);
+                printf("\n");
+            }
+        } else if (stamp_variant == GEMM_TILE_128 || stamp_variant == GEMM_TILE_160) {   // gemm_body: per-CU timelines (who overlaps whom)
           for (size_t ci = 0; ci < cfgs.size(); ++ci) {
             CK(hipMemset(dstamps, 0, (size_t)max_blocks * 16 * 8));
             GemmParams q = p; q.stamps = dstamps; q.order = cfgs[ci].order;
