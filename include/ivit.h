@@ -43,6 +43,10 @@ extern "C" {
 
 #define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
 #define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
+#define IVIT_PRECISION_F16  2   /* IEEE f16 GEMM operands on v_mfma_f32_16x16x32_f16 - the bf16 rate on gfx950, 11 significant
+                                   bits: every node within 1e-3 of the PLAIN f32 forward (the reference's sub(x), main/context.py:79-88,
+                                   returns f32), where bf16 operand rounding alone costs 2e-3.  Range 6.5e4: meant for LayerNorm-ed
+                                   ViT activations; accumulation, statistics and the residual stream stay f32 as in the other modes */
 
 typedef struct ivit_engine ivit_engine;
 

@@ -47,6 +47,27 @@ __device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, r);
 }
 
+// The 16-bit operand type of the data path (IVIT_PRECISION_BF16 / IVIT_PRECISION_F16): the MFMA it is multiplied by, the
+// f32 -> 16-bit rounding (nearest even) and back.  gfx950 issues v_mfma_f32_16x16x32_f16 at the rate of the bf16 form, so
+// the f16 data path costs the same time and carries 11 significant bits instead of 8 (1e-3 against a PLAIN f32 forward).
+struct OpBf16 {
+    static constexpr bool F16 = false;
+    static __device__ __forceinline__ f32x4 mfma(const bf16x8& w, const bf16x8& a, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    static __device__ __forceinline__ bf16_t from_f32(float x) { return f2bf(x); }
+    static __device__ __forceinline__ float to_f32(bf16_t b) { return bf2f(b); }
+};
+struct OpF16 {
+    static constexpr bool F16 = true;
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    static __device__ __forceinline__ f32x4 mfma(const bf16x8& w, const bf16x8& a, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, w), __builtin_bit_cast(h8, a), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+    static __device__ __forceinline__ bf16_t from_f32(float x) { return __builtin_bit_cast(bf16_t, (_Float16)x); }
+    static __device__ __forceinline__ float to_f32(bf16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+};
+
 // fp8 (OCP e4m3fn on gfx950): two f32 -> two fp8 bytes, round to nearest even, SATURATING at +-448
 // (clamped here in software: torch's cast gives NaN above 448 and the oracle clamps the same way).
 constexpr float FP8_MAX = 448.0f;

@@ -39,7 +39,7 @@ static int fail(const char* fmt, ...) {
 extern "C" const char* ivit_last_error(void) { return t_last_error.c_str(); }
 extern "C" int ivit_abi_version(void) { return IVIT_ABI_VERSION; }
 extern "C" const char* ivit_build_info(void) {
-    return "libivit gfx950 (MI355X/CDNA4) bf16/fp8-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_{128x128,160x128,256x256}x64, ivit_gemm_fp8_{128x128,160x128,256x256}x128, ivit_attention_bf16, "
+    return "libivit gfx950 (MI355X/CDNA4) bf16/f16/fp8-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_{128x128,160x128,256x256}x64, ivit_gemm_fp8_{128x128,160x128,256x256}x128, ivit_attention_bf16, "
            "ivit_layernorm, ivit_unfold, ivit_tokens, ivit_transform";
 }
 
@@ -56,7 +56,8 @@ static bool config_ok(const ivit_config* c, std::string* why) {
     if (c->mlp <= 0 || c->mlp % 64) return bad("mlp must be a positive multiple of 64");
     if (c->layers < 0 || c->classes <= 0 || c->max_batch <= 0) return bad("layers/classes/max_batch out of range");
     if (c->dim > 2048) return bad("dim > 2048 unsupported");
-    if (c->precision != IVIT_PRECISION_BF16 && c->precision != IVIT_PRECISION_FP8) return bad("precision must be IVIT_PRECISION_BF16 or IVIT_PRECISION_FP8");
+    if (c->precision != IVIT_PRECISION_BF16 && c->precision != IVIT_PRECISION_FP8 && c->precision != IVIT_PRECISION_F16)
+        return bad("precision must be IVIT_PRECISION_BF16, IVIT_PRECISION_F16 or IVIT_PRECISION_FP8");
     return true;
 }
 
@@ -126,6 +127,7 @@ struct Ws {
 struct ivit_engine {
     ivit_config cfg{};
     int G = 0, Np = 0, N = 0, K = 0, Kp = 0, D = 0, dh = 0;
+    int f16 = 0;                   // IVIT_PRECISION_F16: every 16-bit tensor of the data path is IEEE f16 instead of bf16
     std::mutex mu;
     hipStream_t own_stream = nullptr;
     // sub-batch concurrency: memory-bound kernels (LayerNorm, attention staging, GEMM epilogues) of
@@ -259,6 +261,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     e->G = g; e->Np = g * g; e->N = e->Np + 1; e->D = cfg->dim; e->dh = dh;
     e->K = 3 * cfg->patch * cfg->patch;
     e->Kp = round_up(e->K, 64);
+    e->f16 = cfg->precision == IVIT_PRECISION_F16 ? 1 : 0;
     const int D = e->D, Mlp = cfg->mlp, B = cfg->max_batch;
     int rc = 0;
     auto chk = [&](int r) { rc |= r; };
@@ -273,7 +276,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         const char* gr = getenv("IVIT_GRAPHS");
         e->graphs_on = !(gr && atoi(gr) == 0);
         const char* fl = getenv("IVIT_FOLD_LN");
-        e->fold_ln = !(fl && atoi(fl) == 0) && cfg->precision == IVIT_PRECISION_BF16 && cfg->dim <= 64 * GEMM_LN_SLOTS;
+        e->fold_ln = !(fl && atoi(fl) == 0) && cfg->precision != IVIT_PRECISION_FP8 && cfg->dim <= 64 * GEMM_LN_SLOTS;
         e->fold_always = fl && atoi(fl) == 2;
         if (e->split < 1 || e->split > ivit_engine::MAX_SPLIT) e->split = 1;
         for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
@@ -431,7 +434,7 @@ extern "C" int ivit_set_weight(ivit_engine* e, const char* name, const float* ho
     } else {
         if (elems > e->upload_elems) return fail("ivit_set_weight: staging buffer too small for '%s'", name);
         HIP_TRY(hipMemcpy(e->upload, host, (size_t)elems * 4, hipMemcpyHostToDevice));
-        HIP_TRY(launch_f32_to_bf16(e->upload, s.cols, s.mat->p, s.mat->ld, s.rows, s.cols, e->own_stream));
+        HIP_TRY(launch_f32_to_bf16(e->upload, s.cols, s.mat->p, s.mat->ld, s.rows, s.cols, e->own_stream, e->f16));
         HIP_TRY(hipStreamSynchronize(e->own_stream));
     }
     e->have[name] = true;
@@ -449,8 +452,8 @@ static int require_weights(ivit_engine* e) {
     if (e->fold_ln && !e->fold_ready) {   // one-time preparation of the folded matrices (device already selected by the caller)
         hipStream_t st = e->own_stream;
         for (auto& lw : e->layers) {
-            HIP_TRY(launch_fold_ln_weights(lw.w_in.p, lw.w_in.ld, lw.w_in.rows, lw.w_in.cols, lw.ln1_g, lw.ln1_b, lw.b_in, lw.wf_in.p, lw.s_in, lw.c_in, st));
-            HIP_TRY(launch_fold_ln_weights(lw.w1.p, lw.w1.ld, lw.w1.rows, lw.w1.cols, lw.ln2_g, lw.ln2_b, lw.b1, lw.wf_1.p, lw.s_1, lw.c_1, st));
+            HIP_TRY(launch_fold_ln_weights(lw.w_in.p, lw.w_in.ld, lw.w_in.rows, lw.w_in.cols, lw.ln1_g, lw.ln1_b, lw.b_in, lw.wf_in.p, lw.s_in, lw.c_in, st, e->f16));
+            HIP_TRY(launch_fold_ln_weights(lw.w1.p, lw.w1.ld, lw.w1.rows, lw.w1.cols, lw.ln2_g, lw.ln2_b, lw.b1, lw.wf_1.p, lw.s_1, lw.c_1, st, e->f16));
         }
         HIP_TRY(hipStreamSynchronize(st));
         e->fold_ready = true;
@@ -484,7 +487,7 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
                     int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, const float* rowadd = nullptr,
                     int ldra = 0, int grp_in = 0, int grp_out = 0, int grp_off = 0, const LnFold* lf = nullptr, const char* role = "gemm") {
     GemmParams p{};
-    p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld;
+    p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld; p.f16 = e->f16;
     p.bias = bias; p.epi = epi; p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr;
     p.rowadd = rowadd; p.ldra = ldra; p.grp_in = grp_in; p.grp_out = grp_out; p.grp_off = grp_off;
     if (lf) { p.ln_part = lf->part; p.ln_stats = lf->stats; p.xb = lf->xb; p.ldxb = e->D; p.ln_s = lf->s; p.ln_eps = e->cfg.ln_eps; p.ln_dim = e->D; }
@@ -502,7 +505,7 @@ static int run_layernorm(ivit_engine* e, hipStream_t st, const float* x, int64_t
                          const float* b, bf16_t* o16, float* o32, unsigned char* o8 = nullptr, float scale8 = 1.0f) {
     const int D = e->D;
     ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)rows * D * (4.0 + (o16 ? 2.0 : 0.0) + (o32 ? 4.0 : 0.0) + (o8 ? 1.0 : 0.0)));
-    HIP_TRY(launch_layernorm(x, D, row_stride, rows, D, g, b, e->cfg.ln_eps, o16, D, o32, D, st, o8, e->ld8d, scale8));
+    HIP_TRY(launch_layernorm(x, D, row_stride, rows, D, g, b, e->cfg.ln_eps, o16, D, o32, D, st, o8, e->ld8d, scale8, e->f16));
     return 0;
 }
 
@@ -526,7 +529,7 @@ static int run_attention(ivit_engine* e, const Ws& w, hipStream_t st, int B, uns
     const int D = e->D, M = B * e->N;
     AttnParams ap{};
     ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = D;
-    ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh;
+    ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh; ap.f16 = e->f16;
     ap.scale = 1.0f / std::sqrt((float)e->dh);
     ap.probs = nullptr;
     ap.out8 = out8; ap.ldo8 = e->ld8d; ap.scale8 = scale8;
@@ -601,7 +604,7 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         fold.stats = stats_in ? nullptr : w.ln_stats;      // finished statistics only where ivit_row_stats made them
         if (!stats_in) {
             ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * D * 6.0);
-            HIP_TRY(launch_row_stats(w.x, D, M, D, w.h, D, w.ln_stats, e->cfg.ln_eps, st));
+            HIP_TRY(launch_row_stats(w.x, D, M, D, w.h, D, w.ln_stats, e->cfg.ln_eps, st, e->f16));
         }
         if (tap == TAP_H1) return 0;
         fold.s = lw.s_in;
@@ -663,7 +666,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         }
         {
             ProfScope ps(e, PC_OTHER, st, 0.0, 4.0 * B * 3 * e->cfg.image * e->cfg.image + 2.0 * B * Np * e->Kp);
-            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 1, st));
+            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 1, st, e->f16));
         }
         patches_ready = true;
         s = ST_CONV;
@@ -671,7 +674,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
     if (s == ST_CONV) {
         if (!patches_ready) {
             ProfScope ps(e, PC_OTHER, st, 0.0, 4.0 * B * 3 * e->cfg.image * e->cfg.image + 2.0 * B * Np * e->Kp);
-            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 0, st));
+            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 0, st, e->f16));
         }
         if (end == ST_CONV + 1)
             return run_gemm(e, st, w.patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_F32, out, D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "patch");
@@ -737,7 +740,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
     // heads on an f32 [B,D] input
     {
         ProfScope ps(e, PC_OTHER, st, 0.0, 6.0 * B * D);
-        HIP_TRY(launch_f32_to_bf16(cur, D, w.hc, D, B, D, st));
+        HIP_TRY(launch_f32_to_bf16(cur, D, w.hc, D, B, D, st, e->f16));
     }
     return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "head");
 }
@@ -891,7 +894,7 @@ static int attention_map_locked(ivit_engine* e, int layer, int B, const float* i
     if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
     AttnParams ap{};
     ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = D;
-    ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh;
+    ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh; ap.f16 = e->f16;
     ap.scale = 1.0f / std::sqrt((float)e->dh);
     ap.probs = out;
     ap.out8 = nullptr; ap.ldo8 = 0; ap.scale8 = 1.0f;
@@ -1081,8 +1084,8 @@ extern "C" int ivit_debug_unfold(ivit_engine* e, int batch, const void* in, void
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     if (ws_acquire(e, st)) return 1;
-    HIP_TRY(launch_unfold((const float*)in, e->patches, batch, e->cfg.image, e->cfg.patch, e->Kp, normalise ? 1 : 0, st));
-    HIP_TRY(launch_bf16_to_f32(e->patches, e->Kp, (float*)out, batch * e->Np, e->K, st));
+    HIP_TRY(launch_unfold((const float*)in, e->patches, batch, e->cfg.image, e->cfg.patch, e->Kp, normalise ? 1 : 0, st, e->f16));
+    HIP_TRY(launch_bf16_to_f32(e->patches, e->Kp, (float*)out, batch * e->Np, e->K, st, e->f16));
     return ws_release(e, st);
 }
 

@@ -94,7 +94,7 @@ __device__ __forceinline__ void g256_read_b(const G256Ctx& c, int kt, int h, bf1
 // 16 MFMAs: quadrant (ha, hb) of the wave's 8 x 4 accumulator fragments
 // FP8: the fragments hold e4m3 bytes; the two 16-B k-chunks of a row are the operands of ONE 128-deep
 // scaled-form MFMA (mfma_e4m3_16x16x128), so a quadrant is 8 MFMAs of twice the cycles instead of 16
-template <int HA, int HB, bool FP8 = false>
+template <int HA, int HB, bool FP8 = false, class OP = OpBf16>
 __device__ __forceinline__ void g256_mma(f32x4 (&acc)[8][4], const bf16x8 (&a)[4][2], const bf16x8 (&b)[2][2]) {
     __builtin_amdgcn_s_setprio(1);
     if (FP8) {
@@ -111,7 +111,7 @@ __device__ __forceinline__ void g256_mma(f32x4 (&acc)[8][4], const bf16x8 (&a)[4
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf)
                     acc[HA * 4 + mf][HB * 2 + nf] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nf][kk], a[mf][kk], acc[HA * 4 + mf][HB * 2 + nf], 0, 0, 0);
+                        OP::mfma(b[nf][kk], a[mf][kk], acc[HA * 4 + mf][HB * 2 + nf]);
     }
     __builtin_amdgcn_s_setprio(0);
 }

@@ -33,7 +33,7 @@
 
 namespace ivit {
 
-template <int DBG, bool FP8>
+template <int DBG, bool FP8, class OP = OpBf16>
 __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt, f32x4 (&acc)[8][4],
                                             bf16x8 (&a)[4][2], bf16x8 (&b0)[2][2], bf16x8 (&b1)[2][2]) {
     const int s1 = min(t + 1, last_kt), s2 = min(t + 2, last_kt);   // clamped SOURCE K-tiles
@@ -44,7 +44,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
     IVIT_VMCNT(8);                       // B1(t) landed (read in SR2)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2) g256_mma<0, 0, FP8>(acc, a, b0);
+    if (DBG != 2) g256_mma<0, 0, FP8, OP>(acc, a, b0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- SR2: stage A1(t+1) | read B1
@@ -53,7 +53,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
     IVIT_VMCNT(8);                       // A1(t) landed (read in SR3)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2) g256_mma<0, 1, FP8>(acc, a, b1);
+    if (DBG != 2) g256_mma<0, 1, FP8, OP>(acc, a, b1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- SR3: stage A0(t+2) | read A1 (into the registers A0 just vacated)
@@ -61,7 +61,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
     g256_read_a(c, t, 1, a);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2) g256_mma<1, 1, FP8>(acc, a, b1);
+    if (DBG != 2) g256_mma<1, 1, FP8, OP>(acc, a, b1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- SR4: stage B0(t+2) | nothing to read (B0 is still in registers)
@@ -69,7 +69,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
     IVIT_VMCNT(8);                       // A0(t+1), B0(t+1) landed (read in the next SR1)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2) g256_mma<1, 0, FP8>(acc, a, b0);
+    if (DBG != 2) g256_mma<1, 0, FP8, OP>(acc, a, b0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
 }
@@ -89,7 +89,7 @@ __device__ __forceinline__ void g256s_ktile(const G256Ctx& c, int t, int last_kt
 
 // FP8: A and W are e4m3 BYTE matrices.  A K-tile is 128 bytes of every row either way, so the fp8
 // operands are staged as bf16 matrices of half the row length (lda, ldw % 16 == 0, K % 128 == 0).
-template <int DBG, bool FP8 = false, int EK = 0>
+template <int DBG, bool FP8 = false, int EK = 0, class OP = OpBf16>
 __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     using T = Tile256P;
     IVIT_STAMP(0);
@@ -144,11 +144,11 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     if (late) __builtin_amdgcn_s_barrier();
 
     bf16x8 a[4][2], b0[2][2], b1[2][2];
-    for (int t = 0; t < nt; ++t) g256s_ktile<DBG, FP8>(c, t, last_kt, acc, a, b0, b1);
+    for (int t = 0; t < nt; ++t) g256s_ktile<DBG, FP8, OP>(c, t, last_kt, acc, a, b0, b1);
 
     if (!late) __builtin_amdgcn_s_barrier();
     IVIT_STAMP(2);
-    gemm_epilogue_family<T, EK>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq, tile_stats + wr * 128);
+    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq, tile_stats + wr * 128);
     IVIT_STAMP(3);
     IVIT_VMCNT(0);   // the clamped tail stagings may still be writing LDS
     IVIT_STAMP(4);

@@ -79,7 +79,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int r_local, i
 // the residual loads / stores of many fragments are in flight together.  (With a branch per
 // fragment hipcc emitted load -> s_waitcnt vmcnt(0) -> store 32 times in a row, each paying a full
 // memory latency: ~10 us per 256x256 tile.)  Edge tiles take the guarded path.
-template <class T, bool INTERIOR>
+template <class T, bool INTERIOR, class OP = OpBf16>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base,
                                                    int n_base, int fr, int fq) {
     const int epi = p.epi;
@@ -139,8 +139,8 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { a[r] = gelu_erf(a[r]); b[r] = gelu_erf(b[r]); }
                 }
-                const auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1]), false, false);
-                const auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[2], a[3]), pack_bf16x2(b[2], b[3]), false, false);
+                const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(a[0], a[1]), OP::pack2(b[0], b[1]), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(a[2], a[3]), OP::pack2(b[2], b[3]), false, false);
                 const int n = n_base + (j + (fq & 1)) * 16 + (fq & ~1) * 4;
                 u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
                 *reinterpret_cast<u32x4*>(orow_p + n) = pk;
@@ -165,10 +165,10 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
             } else if (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16) {
                 bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + n;
                 if (full) {
-                    u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    u32x2 pk = {OP::pack2(v[0], v[1]), OP::pack2(v[2], v[3])};
                     *reinterpret_cast<u32x2*>(o) = pk;
                 } else {
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = f2bf(v[r]);
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = OP::from_f32(v[r]);
                 }
             } else {
                 float* o = reinterpret_cast<float*>(p.out) + (size_t)orow * p.ldo + n;
@@ -205,19 +205,19 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
     }
 }
 
-template <class T>
+template <class T, class OP = OpBf16>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base,
                                               int fr, int fq) {
     // wave-uniform: the wave's whole FM*16 x FN*16 patch lies inside the matrix
     const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
-    if (interior) gemm_epilogue_impl<T, true>(p, acc, m_base, n_base, fr, fq);
-    else gemm_epilogue_impl<T, false>(p, acc, m_base, n_base, fr, fq);
+    if (interior) gemm_epilogue_impl<T, true, OP>(p, acc, m_base, n_base, fr, fq);
+    else gemm_epilogue_impl<T, false, OP>(p, acc, m_base, n_base, fr, fq);
 }
 
 // ---- LayerNorm-fold epilogues (their own kernel instantiations: the classic kernels stay as they are).
 // EPI_BIAS_RESID_STATS: residual add as EPI_BIAS_RESID_F32; additionally the bf16 copy of the new rows and, per row,
 // the (sum, M2 about the local mean) of this wave's 64 columns -> ln_part[row][n_base / 64].
-template <class T, bool INTERIOR>
+template <class T, bool INTERIOR, class OP = OpBf16>
 __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
     static_assert(T::FN * 16 == 64, "one statistics slot per wave column");
     const int slot = n_base >> 6;
@@ -254,10 +254,10 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
             bf16_t* ob = p.xb + (size_t)mr * p.ldxb + n;
             if (INTERIOR || (row_ok && n + 3 < p.N)) {
                 *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                u32x2 pk = {OP::pack2(v[0], v[1]), OP::pack2(v[2], v[3])};
                 *reinterpret_cast<u32x2*>(ob) = pk;
             } else if (row_ok) {
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) { o[r] = v[r]; ob[r] = f2bf(v[r]); }
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) { o[r] = v[r]; ob[r] = OP::from_f32(v[r]); }
             }
         }
         sum += __shfl_xor(sum, 16, 64);
@@ -279,7 +279,7 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
 // EPI_LNFOLD_*: v = rstd[m] * (acc - mean[m] * s[n]) + c[n]  (c arrives as `bias`), optional GELU, bf16 out.
 // The row statistics are read from LDS, where ln_tile_stats put them while the first operand tiles were in flight
 // (folding the producers' pairs here, per wave, cost 6-22 us per GEMM; a separate finalize kernel 5 us per LayerNorm).
-template <class T, bool INTERIOR>
+template <class T, bool INTERIOR, class OP = OpBf16>
 __device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
                                                      const float2* tile_stats) {
     // finished row statistics (mean, rstd) of the tile's rows, left in LDS by ln_tile_stats at the start of the kernel
@@ -319,8 +319,8 @@ __device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { a[r] = gelu_erf(a[r]); b[r] = gelu_erf(b[r]); }
                 }
-                const auto lo = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1]), false, false);
-                const auto hi = __builtin_amdgcn_permlane16_swap(pack_bf16x2(a[2], a[3]), pack_bf16x2(b[2], b[3]), false, false);
+                const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(a[0], a[1]), OP::pack2(b[0], b[1]), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(a[2], a[3]), OP::pack2(b[2], b[3]), false, false);
                 const int n = n_base + (j + (fq & 1)) * 16 + (fq & ~1) * 4;
                 u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
                 *reinterpret_cast<u32x4*>(orow_p + n) = pk;
@@ -338,8 +338,8 @@ __device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
             }
             bf16_t* o = orow_p + n;
-            if (n + 3 < p.N) { u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; *reinterpret_cast<u32x2*>(o) = pk; }
-            else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = f2bf(v[r]);
+            if (n + 3 < p.N) { u32x2 pk = {OP::pack2(v[0], v[1]), OP::pack2(v[2], v[3])}; *reinterpret_cast<u32x2*>(o) = pk; }
+            else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = OP::from_f32(v[r]);
         }
     }
 }
@@ -395,18 +395,18 @@ __device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float
 
 // EK = 0: the classic epilogues (kind chosen at run time); 1: EPI_BIAS_RESID_STATS; 2: EPI_LNFOLD_*.
 // (One kernel per classic kind was tried too: no gain at the ViT-B shapes, 5-15 % slower at the ViT-H shapes.)
-template <class T, int EK>
+template <class T, int EK, class OP = OpBf16>
 __device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
                                                      const float2* tile_stats = nullptr) {
     const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
     if (EK == 0) {
-        gemm_epilogue<T>(p, acc, m_base, n_base, fr, fq);
+        gemm_epilogue<T, OP>(p, acc, m_base, n_base, fr, fq);
     } else if (EK == 1) {
-        if (interior) gemm_epilogue_resid_stats<T, true>(p, acc, m_base, n_base, fr, fq);
-        else gemm_epilogue_resid_stats<T, false>(p, acc, m_base, n_base, fr, fq);
+        if (interior) gemm_epilogue_resid_stats<T, true, OP>(p, acc, m_base, n_base, fr, fq);
+        else gemm_epilogue_resid_stats<T, false, OP>(p, acc, m_base, n_base, fr, fq);
     } else {
-        if (interior) gemm_epilogue_lnfold<T, true>(p, acc, m_base, n_base, fr, fq, tile_stats);
-        else gemm_epilogue_lnfold<T, false>(p, acc, m_base, n_base, fr, fq, tile_stats);
+        if (interior) gemm_epilogue_lnfold<T, true, OP>(p, acc, m_base, n_base, fr, fq, tile_stats);
+        else gemm_epilogue_lnfold<T, false, OP>(p, acc, m_base, n_base, fr, fq, tile_stats);
     }
 }
 
@@ -455,7 +455,7 @@ __device__ __forceinline__ void tile_coords_banded(int tile, int tiles_m, int ti
 #define IVIT_BODY_STAMP(slot) do { } while (0)
 #endif
 
-template <class T, bool FP8 = false, int EK = 0>
+template <class T, bool FP8 = false, int EK = 0, class OP = OpBf16>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -534,13 +534,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
                 for (int i = 0; i < T::FM; ++i)
 #pragma unroll
                     for (int j = 0; j < T::FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = OP::mfma(wf[j], af[i], acc[i][j]);
                 __builtin_amdgcn_s_setprio(0);
             }
         }
     }
     IVIT_BODY_STAMP(2);
-    gemm_epilogue_family<T, EK>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
+    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
     IVIT_BODY_STAMP(3);
 #ifdef IVIT_GEMM_ABLATIONS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

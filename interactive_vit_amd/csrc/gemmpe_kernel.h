@@ -53,19 +53,6 @@ __device__ __forceinline__ void pe_asm_load16(f32x4& dst, const void* addr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
 }
 
-// 16-bit operand types of the data path
-struct OpBf16 {
-    static __device__ __forceinline__ f32x4 mfma(const bf16x8& w, const bf16x8& a, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0); }
-    static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
-};
-struct OpF16 {
-    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
-    static __device__ __forceinline__ f32x4 mfma(const bf16x8& w, const bf16x8& a, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, w), __builtin_bit_cast(h8, a), c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
-};
-
 struct PeCtx {
     const GemmParams* p;
     char* smem;
@@ -238,32 +225,41 @@ __device__ __forceinline__ void pe_stats_fold(const PeCtx& c, PeStats& s, int ch
 __device__ __forceinline__ int pe_next_slot(int s) { return s == 2 ? 0 : s + 1; }
 __device__ __forceinline__ int pe_write_slot(int s) { return s == 0 ? 2 : s - 1; }   // (s + 2) % 3
 
-// One K-step = four barrier intervals,
-//      SR0: ds_read the kk = 0 fragments                     M0: 16 MFMAs  (+ epilogue unit U0 of the previous tile)
-//      SR1: ds_read the kk = 1 fragments, statistics loads,   M1: 16 MFMAs  (+ unit U1, + fold of a statistics chunk)
-//           DMA of K-step t + 2, counted wait for K-step t + 1
-// and waves 4-7, which share their SIMDs with waves 0-3, run ONE INTERVAL BEHIND them (they enter the loop through one
-// extra barrier; waves 0-3 make it up at the end): at any time one wave of a SIMD is in an M interval - matrix pipe and the
-// VALU work of the epilogue - while its partner is in an SR interval issuing LDS reads and DMA.  (Without the stagger all
-// eight waves issued their 6 DMA together and then their MFMAs together: 1.27 us per K-step against 0.51 us of MFMA work.)
+// A K-step runs in barrier intervals that alternate "SR" (LDS reads, DMA issue, counted wait) and "M" (MFMAs + the VALU
+// work of the previous tile's epilogue), and waves 4-7, which share their SIMDs with waves 0-3, run ONE INTERVAL BEHIND
+// them (they enter the loop through one extra barrier; waves 0-3 make it up at the end): at any time one wave of a SIMD is
+// in an M interval while its partner is in an SR interval.  (Without the stagger all eight waves issued their DMA
+// together and then their MFMAs together: 1.27 us per K-step against 0.51 us of MFMA work.)
 //
-// Hazards (group 0 runs SR0_t, M0_t, SR1_t, M1_t in intervals 4t .. 4t+3, group 1 one later; barrier k opens interval k):
-//   RAW  stage t+1 is first read in SR0_{t+1} (group 0: interval 4t+4).  Every wave waits for ITS pieces of it at the end of
-//        its SR1_t (intervals 4t+2 / 4t+3), i.e. before barrier 4t+4.
-//   WAR  the DMA of SR1_t overwrites the slot of stage t-1, last read in SR1_{t-1} (group 1: interval 4t-1) and retired by the
-//        lgkmcnt(0) that opens M1_{t-1} (interval 4t), i.e. before barrier 4t+1 < 4t+2, the earliest DMA issue.
+//   thin K-step (the first four of a tile, which carry the epilogue units: 32 fragment registers, `prev` is live)
+//      SR0: DMA of K-step t+2, ds_read kk = 0      M0: 16 MFMAs + unit U0
+//      SR1: ds_read kk = 1, counted wait (t+1)     M1: 16 MFMAs + unit U1
+//   fat K-step (the rest: `prev` is dead, so all 64 fragment registers of a K-step fit)
+//      SR : DMA of K-step t+2, ds_read kk = 0, 1, statistics loads, counted wait (t+1)      M: 32 MFMAs (+ statistics fold)
+// An M interval is one wave's MFMAs only, so the matrix pipe is busy (16 or 32) x 16 cycles per interval of that + ~120
+// cycles of barrier / wait overhead: the fat form is what makes the loop worth having (stamps: tools/gemm_bench).
 //
-// WAIT: vmcnt at the end of SR1 = everything this wave issued after the DMA of K-step t+1 (which SR1_{t-1} issued):
-//       the vector DMA of SR1_{t-1}, the stores of M1_{t-1} and M0_t, the statistics loads and the 6 DMA of SR1_t, its vector DMA.
-// U0 / U1 < 0: no epilogue unit.  LOADS: SR1 loads a statistics chunk into (l0, l1); FOLD: the wait retires the chunk in
-// (f0, f1) - loaded in the previous K-step's SR1, BEFORE that K-step's DMA - and M1 folds it.
-template <class OP, bool GELU, int U0, int U1, bool VEC, int WAIT, bool LOADS, bool FOLD>
-__device__ __forceinline__ void pe_kstep(PeCtx& c, f32x4 (&acc)[4][4], const f32x4 (&prev)[4][4], int pm0, int pn0, const char* tb_prev, int n0,
-                                         char* tb_cur, PeStats& st, int load_chunk, int fold_chunk, int nchunks, int nslots, f32x4& l0, f32x4& l1,
-                                         f32x4& f0, f32x4& f1, const float* chan) {
+// Hazards (barrier k opens interval k; a group's SR intervals end with s_waitcnt lgkmcnt(0), so its LDS reads are retired
+// before the barrier that closes the interval):
+//   RAW  stage t+1 is first read in the first SR interval of K-step t+1.  Every wave waits for ITS pieces of it at the end of
+//        its last SR interval of K-step t, which closes at least one barrier earlier for either group.
+//   WAR  the DMA issued at the start of K-step t overwrites the slot of stage t-1, last read in the last SR interval of
+//        K-step t-1 - for the other group that is the interval just before, retired before the barrier in between.
+// The DMA of stage t+2 is issued at the START of K-step t and waited for at the END of K-step t+1's last SR interval:
+// ~1.5 K-steps of lead, two stages in flight (issuing it next to the wait for stage t+1 left one stage in flight and the
+// loop bound to one DMA round trip of ~2900 cycles per K-step).
+//
+// WAIT: vmcnt = every vector-memory operation this wave issued after the DMA of stage t+1 (K-step t-1's vector DMA, unit
+// stores and statistics loads, this K-step's 6 DMA, vector DMA, first unit store and statistics loads) - minus, when a
+// statistics chunk is folded in this K-step, everything up to and including its loads (they must be retired).
+template <class OP, bool GELU, int U0, int U1, bool VEC, int WAIT>
+__device__ __forceinline__ void pe_kstep_thin(PeCtx& c, f32x4 (&acc)[4][4], const f32x4 (&prev)[4][4], int pm0, int pn0, const char* tb_prev, int n0,
+                                              char* tb_cur) {
     bf16x8 af[4], wf[4];
     // ---- SR0
     PE_STAMP(0);
+    pe_stage(c, pe_write_slot(c.slot));
+    if (VEC) pe_stage_vectors(c, n0, tb_cur);
     pe_read(c, c.slot, 0, af, wf);
     PE_STAMP(1);
     __builtin_amdgcn_s_barrier();
@@ -271,10 +267,6 @@ __device__ __forceinline__ void pe_kstep(PeCtx& c, f32x4 (&acc)[4][4], const f32
     PE_STAMP(2);
     // ---- M0
     if (U0 >= 0) pe_epilogue_unit<OP, GELU, (U0 >= 0 ? U0 : 0)>(c, prev, pm0, pn0, tb_prev);
-#ifdef IVIT_GEMM_ABLATIONS
-    if (c.p->debug == 2) asm volatile("" :: "v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(af[3]), "v"(wf[0]), "v"(wf[1]), "v"(wf[2]), "v"(wf[3]));   // timing ablation: no MFMA
-    else
-#endif
     pe_mma16<OP>(acc, af, wf);
     __builtin_amdgcn_sched_barrier(0);
     PE_STAMP(3);
@@ -282,28 +274,49 @@ __device__ __forceinline__ void pe_kstep(PeCtx& c, f32x4 (&acc)[4][4], const f32
     PE_STAMP(4);
     // ---- SR1
     pe_read(c, c.slot, 1, af, wf);
-    if (LOADS) pe_stats_issue(c, st, load_chunk, nchunks, l0, l1);
-    pe_stage(c, pe_write_slot(c.slot));
-    if (VEC) pe_stage_vectors(c, n0, tb_cur);
     PE_STAMP(5);
-    if (FOLD) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(WAIT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(WAIT) : "memory");
     PE_STAMP(6);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     PE_STAMP(7);
     // ---- M1
     if (U1 >= 0) pe_epilogue_unit<OP, GELU, (U1 >= 0 ? U1 : 0)>(c, prev, pm0, pn0, tb_prev);
-    if (FOLD) { if (fold_chunk < nchunks) pe_stats_fold(c, st, fold_chunk, nslots, f0, f1, chan); }
-#ifdef IVIT_GEMM_ABLATIONS
-    if (c.p->debug == 2) asm volatile("" :: "v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(af[3]), "v"(wf[0]), "v"(wf[1]), "v"(wf[2]), "v"(wf[3]));
-    else
-#endif
     pe_mma16<OP>(acc, af, wf);
     __builtin_amdgcn_sched_barrier(0);
     PE_STAMP(8);
     __builtin_amdgcn_s_barrier();
     PE_STAMP(9);
+    c.slot = pe_next_slot(c.slot);
+}
+
+// LOADS: the SR interval loads a statistics chunk into (l0, l1); FOLD: the wait retires the chunk in (f0, f1) - loaded in the
+// previous K-step - and the M interval folds it.
+template <class OP, int WAIT, bool LOADS, bool FOLD>
+__device__ __forceinline__ void pe_kstep_fat(PeCtx& c, f32x4 (&acc)[4][4], PeStats& st, int load_chunk, int fold_chunk, int nchunks, int nslots,
+                                             f32x4& l0, f32x4& l1, f32x4& f0, f32x4& f1, const float* chan) {
+    bf16x8 af0[4], wf0[4], af1[4], wf1[4];
+    // ---- SR
+    PE_STAMP(0);
+    pe_stage(c, pe_write_slot(c.slot));
+    pe_read(c, c.slot, 0, af0, wf0);
+    pe_read(c, c.slot, 1, af1, wf1);
+    if (LOADS) pe_stats_issue(c, st, load_chunk, nchunks, l0, l1);
+    PE_STAMP(1);
+    if (FOLD) asm volatile("s_waitcnt vmcnt(%2) lgkmcnt(0)" : "+v"(f0), "+v"(f1) : "n"(WAIT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(WAIT) : "memory");
+    PE_STAMP(2);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PE_STAMP(3);
+    // ---- M
+    if (FOLD) { if (fold_chunk < nchunks) pe_stats_fold(c, st, fold_chunk, nslots, f0, f1, chan); }
+    pe_mma16<OP>(acc, af0, wf0);
+    pe_mma16<OP>(acc, af1, wf1);
+    __builtin_amdgcn_sched_barrier(0);
+    PE_STAMP(4);
+    __builtin_amdgcn_s_barrier();
+    PE_STAMP(5);
     c.slot = pe_next_slot(c.slot);
 }
 
@@ -360,6 +373,10 @@ __device__ __forceinline__ void gemmpe_body(const GemmParams& p, char* smem) {
     c.d_kt = 0;
     c.slot = 0;
     c.stamp_now = false;
+#ifdef IVIT_GEMM_ABLATIONS
+    if (p.stamps && threadIdx.x == 0)   // which XCD runs this block (is it blockIdx % 8 ?)
+        p.stamps[(size_t)blockIdx.x * 128 + 15] = 1 + (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15);
+#endif
     pe_stage(c, 0);
     pe_stage(c, 1);
     IVIT_VMCNT(6);                                       // K-step 0 landed for this wave
@@ -367,9 +384,9 @@ __device__ __forceinline__ void gemmpe_body(const GemmParams& p, char* smem) {
     const bool late = c.wave >= 4;
     if (late) __builtin_amdgcn_s_barrier();              // waves 4-7 start one interval late
 
-    // Statistics pipeline of a tile: chunk j (4 slots = two 16-byte loads) is loaded in SR1 of K-step 4 + j and folded in M1
-    // of K-step 5 + j.  Vector-memory operations besides the 6 operand DMA of a K-step: a statistics chunk 2 loads, an
-    // epilogue unit 1 store, the vector DMA 1.
+    // Statistics pipeline of a tile: chunk j (4 slots = two 16-byte loads) is loaded in the SR interval of K-step 4 + j and
+    // folded in the M interval of K-step 5 + j.  Vector-memory operations besides the 6 operand DMA of a K-step: a statistics
+    // chunk 2 loads, an epilogue unit 1 store, the vector DMA 1.
     int pm0 = 0, pn0 = 0;
     for (int k = 0; k < c.n_my; ++k) {
         int m0, n0;
@@ -381,39 +398,41 @@ __device__ __forceinline__ void gemmpe_body(const GemmParams& p, char* smem) {
         st.mean = 0.f; st.m2 = 0.f;
         st.src = reinterpret_cast<const char*>(p.ln_part) + (size_t)min(m0 + row_t, p.M - 1) * (GEMM_LN_SLOTS * 8);
         f32x4 ra0 = {0.f, 0.f, 0.f, 0.f}, ra1 = ra0, rb0 = ra0, rb1 = ra0;   // two chunks of statistics loads in flight (sets a / b)
-#define PE_ARGS c, acc, prev, pm0, pn0, tb_prev, n0, tb_cur, st
+#define PE_THIN c, acc, prev, pm0, pn0, tb_prev, n0, tb_cur
+#define PE_FAT c, acc, st
         if (k == 0) {   // first tile of the workgroup: nothing to drain
-            pe_kstep<OP, GELU, -1, -1, true, 7, false, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);    // 6 + the vector DMA
-            pe_kstep<OP, GELU, -1, -1, false, 7, false, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);   // vector DMA + 6
-            pe_kstep<OP, GELU, -1, -1, false, 6, false, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);
-            pe_kstep<OP, GELU, -1, -1, false, 6, false, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);
-            pe_kstep<OP, GELU, -1, -1, false, 8, true, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);    // K-step 4: loads chunk 0 -> a; 2 + 6
+            pe_kstep_thin<OP, GELU, -1, -1, true, 7>(PE_THIN);     // 6 + the vector DMA
+            pe_kstep_thin<OP, GELU, -1, -1, false, 7>(PE_THIN);    // vector DMA + 6
+            pe_kstep_thin<OP, GELU, -1, -1, false, 6>(PE_THIN);
+            pe_kstep_thin<OP, GELU, -1, -1, false, 6>(PE_THIN);
+            pe_kstep_fat<OP, 8, true, false>(PE_FAT, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);                    // K-step 4: chunk 0 -> a; 6 + 2
         } else {        // steady state: the previous tile's epilogue, one unit per M interval
-            pe_kstep<OP, GELU, 0, 1, true, 8, false, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);      // store of M0 + 6 + vector DMA
-            pe_kstep<OP, GELU, 2, 3, false, 9, false, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);     // vector DMA + stores of M1, M0 + 6
-            pe_kstep<OP, GELU, 4, 5, false, 8, false, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);     // 2 stores + 6
-            pe_kstep<OP, GELU, 6, 7, false, 8, false, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);
-            pe_kstep<OP, GELU, -1, -1, false, 9, true, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);    // K-step 4: store of M1 + 2 loads + 6
+            pe_kstep_thin<OP, GELU, 0, 1, true, 8>(PE_THIN);       // 6 + vector DMA + store of M0
+            pe_kstep_thin<OP, GELU, 2, 3, false, 10>(PE_THIN);     // vector DMA + 2 stores, 6 + store of M0
+            pe_kstep_thin<OP, GELU, 4, 5, false, 9>(PE_THIN);      // 2 stores, 6 + 1
+            pe_kstep_thin<OP, GELU, 6, 7, false, 9>(PE_THIN);
+            pe_kstep_fat<OP, 10, true, false>(PE_FAT, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);                   // K-step 4: 2 stores, 6 + 2 loads
         }
-        // K-steps 5 .. 3 + nch: load chunk j + 1, fold chunk j (the wait leaves this K-step's 2 loads and 6 DMA outstanding)
+        // K-steps 5 .. 3 + nch: load chunk j + 1, fold chunk j (the wait leaves this K-step's 6 DMA and 2 loads outstanding)
         int t = 5;
         for (int j = 0; j + 2 < nch; j += 2, t += 2) {
-            pe_kstep<OP, GELU, -1, -1, false, 8, true, true>(PE_ARGS, j + 1, j, nchunks, nslots, rb0, rb1, ra0, ra1, chan);
-            pe_kstep<OP, GELU, -1, -1, false, 8, true, true>(PE_ARGS, j + 2, j + 1, nchunks, nslots, ra0, ra1, rb0, rb1, chan);
+            pe_kstep_fat<OP, 8, true, true>(PE_FAT, j + 1, j, nchunks, nslots, rb0, rb1, ra0, ra1, chan);
+            pe_kstep_fat<OP, 8, true, true>(PE_FAT, j + 2, j + 1, nchunks, nslots, ra0, ra1, rb0, rb1, chan);
         }
-        pe_kstep<OP, GELU, -1, -1, false, 8, true, true>(PE_ARGS, nch - 1, nch - 2, nchunks, nslots, rb0, rb1, ra0, ra1, chan);     // K-step 3 + nch: the last load
-        pe_kstep<OP, GELU, -1, -1, false, 6, false, true>(PE_ARGS, 0, nch - 1, nchunks, nslots, ra0, ra1, rb0, rb1, chan);         // K-step 4 + nch: the last fold
+        pe_kstep_fat<OP, 8, true, true>(PE_FAT, nch - 1, nch - 2, nchunks, nslots, rb0, rb1, ra0, ra1, chan);              // K-step 3 + nch: the last load
+        pe_kstep_fat<OP, 6, false, true>(PE_FAT, 0, nch - 1, nchunks, nslots, ra0, ra1, rb0, rb1, chan);                   // K-step 4 + nch: the last fold
         t += 2;
         for (; t < c.nt; ++t) {                           // the rest of the tile: operand ring only
 #ifdef IVIT_GEMM_ABLATIONS
             c.stamp_now = p.stamps && k == 1 && t == c.nt - 2;
 #endif
-            pe_kstep<OP, GELU, -1, -1, false, 6, false, false>(PE_ARGS, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);
+            pe_kstep_fat<OP, 6, false, false>(PE_FAT, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);
         }
 #ifdef IVIT_GEMM_ABLATIONS
         c.stamp_now = false;
 #endif
-#undef PE_ARGS
+#undef PE_THIN
+#undef PE_FAT
         // statistics of this tile's rows -> its tile buffer (read by the epilogue units during the NEXT tile's K-steps,
         // behind several barriers)
         {

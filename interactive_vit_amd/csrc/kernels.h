@@ -26,6 +26,7 @@ struct GemmParams {
     const bf16_t* A; int lda;     // [M, K] bf16 row-major, rows readable up to round_up(M,256)+256
     const bf16_t* W; int ldw;     // [N, K] bf16 row-major, rows readable up to round_up(N,256)
     int M, N, K;                  // K % 64 == 0 (operands zero-padded); fp8 operands: K % 128 == 0
+    int f16;                      // 0: A, W and 16-bit outputs are bf16; 1: IEEE f16 (IVIT_PRECISION_F16)
     const float* colscale;        // fp8 operands: acc *= colscale[n] (= activation scale x weight-row scale) before the bias
     float out_scale;              // EPI_BIAS_GELU_FP8: 1 / (scale of the fp8 output tensor)
     const float* bias;            // [N]
@@ -70,6 +71,7 @@ struct AttnParams {
     bf16_t* out; int ldo;          // [B*N, D] bf16
     int batch, tokens, heads, head_dim;
     float scale;                   // 1/sqrt(dh)
+    int f16;                       // 0: q|k|v, P and the output are bf16; 1: IEEE f16
     float* probs;                  // nullptr, or f32 [B, H, N, N]: write the attention probabilities instead of P.V
     unsigned char* out8; int ldo8; // nullptr, or e4m3 [B*N, D]: write sat_fp8(O * scale8) INSTEAD of the bf16 output
     float scale8;
@@ -84,7 +86,7 @@ hipError_t launch_transform(const float* in, float* out, int batch, int image, h
 hipError_t launch_preprocess(const float* in, int H, int W, float* out, int batch, int image, int resize, hipStream_t s);
 // f32 image -> bf16 unfold matrix [B*Np, kpad] (columns >= 3p^2 zero); normalise fuses the transform
 hipError_t launch_unfold(const float* in, bf16_t* out, int batch, int image, int patch, int kpad,
-                         int normalise, hipStream_t s);
+                         int normalise, hipStream_t s, int f16 = 0);
 // out[b,0,:] = cls + pos[0]; out[b,1+n,:] = in[b,n,:] + pos[1+n]   (in == nullptr: class rows only)
 hipError_t launch_tokens(const float* in, const float* cls, const float* pos, float* out, int batch,
                          int patches, int dim, hipStream_t s);
@@ -93,7 +95,7 @@ hipError_t launch_tokens(const float* in, const float* cls, const float* pos, fl
 // optional third output: e4m3 (out_fp8, ld = ldo8 bytes) = sat_fp8(y * scale8)
 hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, bf16_t* out_bf16, int ldo16, float* out_f32,
-                            int ldo32, hipStream_t s, unsigned char* out_fp8 = nullptr, int ldo8 = 0, float scale8 = 1.0f);
+                            int ldo32, hipStream_t s, unsigned char* out_fp8 = nullptr, int ldo8 = 0, float scale8 = 1.0f, int f16 = 0);
 // fp8 support: tensor amax (atomicMax into *out, which the caller zeroes), per-row weight quantisation, vector scale
 hipError_t launch_amax_bf16(const bf16_t* in, int ld, int rows, int cols, float* out, hipStream_t s);
 hipError_t launch_quantize_weight_fp8(const bf16_t* w, int ld, int rows, int cols, unsigned char* w8, int ld8, float* rowscale,
@@ -102,15 +104,15 @@ hipError_t launch_scale_vec(const float* in, float a, float* out, int n, hipStre
 // LayerNorm folded into the GEMM that follows it: weight preparation and row statistics
 constexpr int GEMM_LN_SLOTS = 32;   // 64-column statistics slots per row (dim <= 2048)
 hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, const float* gamma, const float* beta, const float* bias,
-                                  bf16_t* wf, float* s_out, float* c_out, hipStream_t s);
-hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* stats, float eps, hipStream_t s);
+                                  bf16_t* wf, float* s_out, float* c_out, hipStream_t s, int f16 = 0);
+hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* stats, float eps, hipStream_t s, int f16 = 0);
 // atomicMax(*out, max over rows of |mean| / sqrt(var + eps)) of a [rows, dim] f32 matrix; the caller zeroes *out
 hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, float eps, float* out, hipStream_t s);
 // strided row gather: out[i,:] = in[i*row_stride, :dim]  (the `cls` node)
 hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, int rows, int dim, hipStream_t s);
 // f32 [rows, cols] -> bf16 [rows, ldo] (columns >= cols zero)
-hipError_t launch_f32_to_bf16(const float* in, int ldi, bf16_t* out, int ldo, int rows, int cols, hipStream_t s);
+hipError_t launch_f32_to_bf16(const float* in, int ldi, bf16_t* out, int ldo, int rows, int cols, hipStream_t s, int f16 = 0);
 // bf16 [rows, ldi] -> f32 [rows, cols]
-hipError_t launch_bf16_to_f32(const bf16_t* in, int ldi, float* out, int rows, int cols, hipStream_t s);
+hipError_t launch_bf16_to_f32(const bf16_t* in, int ldi, float* out, int rows, int cols, hipStream_t s, int f16 = 0);
 
 }  // namespace ivit

@@ -81,7 +81,8 @@ __device__ __forceinline__ void att_stage(char* lds, const bf16_t* src0, int ld,
     }
 }
 
-template <int DH, int NKF, bool ODD, bool PROBS>
+// OP: the 16-bit type of q|k|v, of the softmax numerators fed to P.V and of the output (OpBf16 / OpF16, common.h)
+template <int DH, int NKF, bool ODD, bool PROBS, class OP>
 __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     using L = AttLayout<DH, NKF, ODD>;
     constexpr int ATT_DH = DH;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
                 const int ch = kk * 4 + g;
                 bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + L::k_off(key, ch < L::CHUNKS ? ch : 0));
                 if (ch >= L::CHUNKS) kf = zero_frag;
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], a, 0, 0, 0);
+                a = OP::mfma(kf, qf[kk], a);
             }
             s[f] = a;
         }
@@ -207,10 +208,10 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
         for (int st = 0; st < NKF / 2; ++st) {
             const f32x4 p0 = s[2 * st], p1 = s[2 * st + 1];
             union { bf16x8 v; unsigned int u[4]; } pk;
-            pk.u[0] = pack_bf16x2(p0[0], p0[1]);
-            pk.u[1] = pack_bf16x2(p0[2], p0[3]);
-            pk.u[2] = pack_bf16x2(p1[0], p1[1]);
-            pk.u[3] = pack_bf16x2(p1[2], p1[3]);
+            pk.u[0] = OP::pack2(p0[0], p0[1]);
+            pk.u[1] = OP::pack2(p0[2], p0[3]);
+            pk.u[2] = OP::pack2(p1[0], p1[1]);
+            pk.u[3] = OP::pack2(p1[2], p1[3]);
             const int key_lo = 32 * st + 4 * g + tq;       // first half of the k-slots; second half = +16 keys
 #pragma unroll
             for (int d = 0; d < L::NDB; ++d) {
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
                 vf.h2[0] = lds_read_tr16(lo);
                 if (ODD && st == NKF / 2 - 1) vf.h2[1] = bf16x4{0, 0, 0, 0};   // the fragment that is not in LDS: its P is exactly 0
                 else vf.h2[1] = lds_read_tr16(hi);
-                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, o[d], 0, 0, 0);
+                o[d] = OP::mfma(vf.v, pk.v, o[d]);
             }
         }
 
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
             bf16_t* orow = p.out + (row0 + q) * p.ldo + h * ATT_DH + g * 4;
 #pragma unroll
             for (int d = 0; d < L::NDB; ++d) {
-                u32x2 pk2 = {pack_bf16x2(o[d][0] * inv, o[d][1] * inv), pack_bf16x2(o[d][2] * inv, o[d][3] * inv)};
+                u32x2 pk2 = {OP::pack2(o[d][0] * inv, o[d][1] * inv), OP::pack2(o[d][2] * inv, o[d][3] * inv)};
                 *reinterpret_cast<u32x2*>(orow + d * 16) = pk2;
             }
         }
@@ -253,10 +254,10 @@ bool attention_supported(int tokens, int head_dim) {
     return false;
 }
 
-template <int DH, int NKF, bool ODD, bool PROBS>
-static hipError_t launch_nkf_impl(const AttnParams& p, hipStream_t stream) {
+template <int DH, int NKF, bool ODD, bool PROBS, class OP>
+static hipError_t launch_nkf_op(const AttnParams& p, hipStream_t stream) {
     using L = AttLayout<DH, NKF, ODD>;
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ivit_attention_bf16<DH, NKF, ODD, PROBS>), L::LDS_BYTES);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ivit_attention_bf16<DH, NKF, ODD, PROBS, OP>), L::LDS_BYTES);
     if (e != hipSuccess) return e;
     const int blocks = ceil_div(p.tokens, 16);
     // every wave gets at least one 16-query block.  (Measured at 197 keys, three 5-wave workgroups per CU -
@@ -264,8 +265,13 @@ static hipError_t launch_nkf_impl(const AttnParams& p, hipStream_t stream) {
     // launch moves 58 + 19 MB in 25 us and is bound by that, not by the 1.5-round grid.)
     const int waves = std::min(8, blocks);
     dim3 grid(1, p.heads, p.batch);
-    hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, ODD, PROBS>), grid, dim3(waves * 64), L::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, ODD, PROBS, OP>), grid, dim3(waves * 64), L::LDS_BYTES, stream, p);
     return hipGetLastError();
+}
+
+template <int DH, int NKF, bool ODD, bool PROBS>
+static hipError_t launch_nkf_impl(const AttnParams& p, hipStream_t stream) {
+    return p.f16 ? launch_nkf_op<DH, NKF, ODD, PROBS, OpF16>(p, stream) : launch_nkf_op<DH, NKF, ODD, PROBS, OpBf16>(p, stream);
 }
 
 template <int DH, int NKF>

@@ -61,6 +61,23 @@ __global__ __launch_bounds__(TilePE::THREADS, 2) void ivit_gemm_bf16_256x128x64_
     gemmpe_body<OpBf16, true>(p, smem);
 }
 
+// f16 operands (IVIT_PRECISION_F16): the same bodies on v_mfma_f32_16x16x32_f16 with f16 outputs (same rate as bf16, 11 bits)
+#define IVIT_F16_KERNEL(NAME, THREADS_, BODY)                                                  \
+    __global__ __launch_bounds__(THREADS_, 2) void NAME(GemmParams p) {                        \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
+        BODY;                                                                                  \
+    }
+IVIT_F16_KERNEL(ivit_gemm_f16_128x128x64, Tile128::THREADS, (gemm_body<Tile128, false, 0, OpF16>(p, smem)))
+IVIT_F16_KERNEL(ivit_gemm_f16_128x128x64_rs, Tile128::THREADS, (gemm_body<Tile128, false, 1, OpF16>(p, smem)))
+IVIT_F16_KERNEL(ivit_gemm_f16_128x128x64_lf, Tile128::THREADS, (gemm_body<Tile128, false, 2, OpF16>(p, smem)))
+IVIT_F16_KERNEL(ivit_gemm_f16_160x128x64, Tile160::THREADS, (gemm_body<Tile160, false, 0, OpF16>(p, smem)))
+IVIT_F16_KERNEL(ivit_gemm_f16_160x128x64_rs, Tile160::THREADS, (gemm_body<Tile160, false, 1, OpF16>(p, smem)))
+IVIT_F16_KERNEL(ivit_gemm_f16_160x128x64_lf, Tile160::THREADS, (gemm_body<Tile160, false, 2, OpF16>(p, smem)))
+IVIT_F16_KERNEL(ivit_gemm_f16_256x256x64_stag, Tile256P::THREADS, (gemm256s_body<0, false, 0, OpF16>(p, smem)))
+IVIT_F16_KERNEL(ivit_gemm_f16_256x256x64_stag_rs, Tile256P::THREADS, (gemm256s_body<0, false, 1, OpF16>(p, smem)))
+IVIT_F16_KERNEL(ivit_gemm_f16_256x256x64_stag_lf, Tile256P::THREADS, (gemm256s_body<0, false, 2, OpF16>(p, smem)))
+#undef IVIT_F16_KERNEL
+
 // fp8 (e4m3) operands: same tiles, K-tile of 128 elements, two fp8 MFMA steps per 16-B fragment
 __global__ __launch_bounds__(Tile128::THREADS, 2) void ivit_gemm_fp8_128x128x128(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,6 +234,7 @@ static int device_cu_count() {
 bool gemm_pe_supported(const GemmParams& p) {
     const bool fold = p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16;
     if (!fold && p.epi != EPI_BIAS_BF16 && p.epi != EPI_BIAS_GELU_BF16) return false;
+    if (p.f16) return false;   // bf16 instantiations only
     if (p.N % TilePE::BN || p.K % GEMM_BK || p.colscale || p.grp_in || !p.ln_s || (p.ldo % 8)) return false;
     const int nt = p.K / GEMM_BK;
     if (nt < TilePE::MIN_KT) return false;
@@ -253,6 +271,17 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
         if (p.grp_in != 0) return hipErrorInvalidValue;
         if (family == 1 && (!p.ln_part || !p.resid || !p.xb || (p.ldxb % 4))) return hipErrorInvalidValue;
         if (family == 2 && ((!p.ln_stats && !p.ln_part) || !p.ln_s || p.ln_dim <= 0 || p.ln_dim > 64 * GEMM_LN_SLOTS)) return hipErrorInvalidValue;
+    }
+    if (p.f16) {   // f16 operands: the three product tiles, every epilogue family
+        const int extra = family == 2 ? 8 : 0;   // _lf kernels keep (mean, rstd) of their tile's rows in BM * 8 bytes of LDS behind the operand stages
+        switch (variant) {
+            case GEMM_TILE_128: return launch_tile<Tile128>(family == 0 ? ivit_gemm_f16_128x128x64 : family == 1 ? ivit_gemm_f16_128x128x64_rs : ivit_gemm_f16_128x128x64_lf, p, stream, Tile128::BM * extra);
+            case GEMM_TILE_160: return launch_tile<Tile160>(family == 0 ? ivit_gemm_f16_160x128x64 : family == 1 ? ivit_gemm_f16_160x128x64_rs : ivit_gemm_f16_160x128x64_lf, p, stream, Tile160::BM * extra);
+            case GEMM_TILE_256S: return launch_tile<Tile256P>(family == 0 ? ivit_gemm_f16_256x256x64_stag : family == 1 ? ivit_gemm_f16_256x256x64_stag_rs : ivit_gemm_f16_256x256x64_stag_lf, p, stream, Tile256P::BM * extra);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (family) {
         switch (variant) {   // _lf kernels keep (mean, rstd) of their tile's rows in BM * 8 bytes of LDS behind the operand stages
             case GEMM_TILE_128: return family == 1 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_rs, p, stream) : launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_lf, p, stream, Tile128::BM * 8);
             case GEMM_TILE_160: return family == 1 ? launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_rs, p, stream) : launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_lf, p, stream, Tile160::BM * 8);
@@ -307,7 +336,11 @@ const char* gemm_kernel_name(const GemmParams& p) {
         {"ivit_gemm_bf16_128x128x64", "ivit_gemm_bf16_128x128x64_rs", "ivit_gemm_bf16_128x128x64_lf"},
         {"ivit_gemm_bf16_160x128x64", "ivit_gemm_bf16_160x128x64_rs", "ivit_gemm_bf16_160x128x64_lf"},
         {"ivit_gemm_bf16_256x256x64_stag", "ivit_gemm_bf16_256x256x64_stag_rs", "ivit_gemm_bf16_256x256x64_stag_lf"}};
-    return names[v == GEMM_TILE_128 ? 0 : v == GEMM_TILE_160 ? 1 : 2][family];
+    static const char* names16[3][3] = {
+        {"ivit_gemm_f16_128x128x64", "ivit_gemm_f16_128x128x64_rs", "ivit_gemm_f16_128x128x64_lf"},
+        {"ivit_gemm_f16_160x128x64", "ivit_gemm_f16_160x128x64_rs", "ivit_gemm_f16_160x128x64_lf"},
+        {"ivit_gemm_f16_256x256x64_stag", "ivit_gemm_f16_256x256x64_stag_rs", "ivit_gemm_f16_256x256x64_stag_lf"}};
+    return (p.f16 ? names16 : names)[v == GEMM_TILE_128 ? 0 : v == GEMM_TILE_160 ? 1 : 2][family];
 }
 
 hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {

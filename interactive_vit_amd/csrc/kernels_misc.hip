@@ -5,6 +5,11 @@
 
 namespace ivit {
 
+// the 16-bit operand type picked at run time (memory-bound kernels: a uniform select costs nothing)
+__device__ __forceinline__ unsigned int pack16x2(int f16, float lo, float hi) { return f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
+__device__ __forceinline__ float dec16(int f16, bf16_t b) { return f16 ? OpF16::to_f32(b) : bf2f(b); }
+__device__ __forceinline__ bf16_t enc16(int f16, float x) { return f16 ? OpF16::from_f32(x) : f2bf(x); }
+
 __constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 
@@ -102,7 +107,7 @@ hipError_t launch_preprocess(const float* in, int H, int W, float* out, int batc
 // sources are 8 consecutive pixels of one image row (two float4 loads); otherwise each element is
 // located through unfold_offset().  Columns k >= 3p^2 (K padding up to a multiple of 64) are zero.
 __global__ void ivit_unfold(const float* __restrict__ in, bf16_t* __restrict__ out, int batch, int image,
-                            int patch, int kpad, int normalise) {
+                            int patch, int kpad, int normalise, int f16) {
     const int g = image / patch;
     const int np = g * g;
     const int kreal = 3 * patch * patch;
@@ -141,16 +146,16 @@ __global__ void ivit_unfold(const float* __restrict__ in, bf16_t* __restrict__ o
                 v[e] = x;
             }
         }
-        u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        u32x4 pk = {pack16x2(f16, v[0], v[1]), pack16x2(f16, v[2], v[3]), pack16x2(f16, v[4], v[5]), pack16x2(f16, v[6], v[7])};
         *reinterpret_cast<u32x4*>(out + row * kpad + k0) = pk;
     }
 }
 
 hipError_t launch_unfold(const float* in, bf16_t* out, int batch, int image, int patch, int kpad, int normalise,
-                         hipStream_t s) {
+                         hipStream_t s, int f16) {
     const int g = image / patch;
     const int64_t total = (int64_t)batch * g * g * (kpad / 8);
-    hipLaunchKernelGGL(ivit_unfold, dim3(ew_grid(total)), dim3(EW_THREADS), 0, s, in, out, batch, image, patch, kpad, normalise);
+    hipLaunchKernelGGL(ivit_unfold, dim3(ew_grid(total)), dim3(EW_THREADS), 0, s, in, out, batch, image, patch, kpad, normalise, f16);
     return hipGetLastError();
 }
 
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
                                                       int dim, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
                                                       bf16_t* __restrict__ o16, int ldo16, float* __restrict__ o32,
-                                                      int ldo32, unsigned char* __restrict__ o8, int ldo8, float scale8) {
+                                                      int ldo32, unsigned char* __restrict__ o8, int ldo8, float scale8, int f16) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
     if (row0 >= rows) return;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
                 y.w = (v[r][i].w - mean) * rstd * gm[i].w + bt[i].w;
                 if (o32) reinterpret_cast<float4*>(o32 + (size_t)row * ldo32)[c] = y;
                 if (o16) {
-                    u32x2 pk = {pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
+                    u32x2 pk = {pack16x2(f16, y.x, y.y), pack16x2(f16, y.z, y.w)};
                     reinterpret_cast<u32x2*>(o16 + (size_t)row * ldo16)[c] = pk;
                 }
                 if (o8)   // e4m3 with the tensor's calibrated scale (scale8 = 1 / scale)
@@ -259,12 +264,12 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
 
 hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, bf16_t* o16, int ldo16, float* o32, int ldo32,
-                            hipStream_t s, unsigned char* o8, int ldo8, float scale8) {
+                            hipStream_t s, unsigned char* o8, int ldo8, float scale8, int f16) {
     if (dim % 4 || dim > 64 * 4 * 8) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
     const dim3 grid(ceil_div(rows, 4 * LN_RPW)), block(256);
     const int vpl = ceil_div(dim / 4, 64);
-#define IVIT_LN(V) hipLaunchKernelGGL(ivit_layernorm<V>, grid, block, 0, s, x, ldx, row_stride, rows, dim, gamma, beta, eps, o16, ldo16, o32, ldo32, o8, ldo8, scale8)
+#define IVIT_LN(V) hipLaunchKernelGGL(ivit_layernorm<V>, grid, block, 0, s, x, ldx, row_stride, rows, dim, gamma, beta, eps, o16, ldo16, o32, ldo32, o8, ldo8, scale8, f16)
     if (vpl <= 1) IVIT_LN(1);
     else if (vpl <= 2) IVIT_LN(2);
     else if (vpl <= 3) IVIT_LN(3);
@@ -282,7 +287,7 @@ hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int row
 __global__ __launch_bounds__(256) void ivit_fold_ln_weights(const bf16_t* __restrict__ w, int ld, int rows, int cols,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ bias, bf16_t* __restrict__ wf, float* __restrict__ s_out,
-                                                            float* __restrict__ c_out) {
+                                                            float* __restrict__ c_out, int f16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -292,9 +297,9 @@ __global__ __launch_bounds__(256) void ivit_fold_ln_weights(const bf16_t* __rest
     for (int k = lane; k < ld; k += 64) {
         float folded = 0.f;
         if (k < cols) {
-            const float wv = bf2f(wr[k]);
-            const bf16_t q = f2bf(wv * gamma[k]);
-            folded = bf2f(q);
+            const float wv = dec16(f16, wr[k]);
+            const bf16_t q = enc16(f16, wv * gamma[k]);
+            folded = dec16(f16, q);
             c = fmaf(beta[k], wv, c);
             fr[k] = q;
         } else {
@@ -308,8 +313,8 @@ __global__ __launch_bounds__(256) void ivit_fold_ln_weights(const bf16_t* __rest
 }
 
 hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, const float* gamma, const float* beta, const float* bias,
-                                  bf16_t* wf, float* s_out, float* c_out, hipStream_t s) {
-    hipLaunchKernelGGL(ivit_fold_ln_weights, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w, ld, rows, cols, gamma, beta, bias, wf, s_out, c_out);
+                                  bf16_t* wf, float* s_out, float* c_out, hipStream_t s, int f16) {
+    hipLaunchKernelGGL(ivit_fold_ln_weights, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w, ld, rows, cols, gamma, beta, bias, wf, s_out, c_out, f16);
     return hipGetLastError();
 }
 
@@ -317,7 +322,7 @@ hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, c
 // layer of a call): what the folded GEMMs read.  One wave per row, two-pass statistics as in ivit_layernorm.
 template <int VPL>
 __global__ __launch_bounds__(256) void ivit_row_stats(const float* __restrict__ x, int ldx, int rows, int dim, bf16_t* __restrict__ xb, int ldxb,
-                                                      float2* __restrict__ stats, float eps) {
+                                                      float2* __restrict__ stats, float eps, int f16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256) void ivit_row_stats(const float* __restrict__ 
         if (c < d4) {
             const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
             sq += (a * a + b * b) + (cc * cc + d * d);
-            u32x2 pk = {pack_bf16x2(v[i].x, v[i].y), pack_bf16x2(v[i].z, v[i].w)};
+            u32x2 pk = {pack16x2(f16, v[i].x, v[i].y), pack16x2(f16, v[i].z, v[i].w)};
             reinterpret_cast<u32x2*>(xb + (size_t)row * ldxb)[c] = pk;
         }
     }
@@ -347,12 +352,12 @@ __global__ __launch_bounds__(256) void ivit_row_stats(const float* __restrict__ 
     if (lane == 0) stats[row] = make_float2(mean, rstd);
 }
 
-hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* stats, float eps, hipStream_t s) {
+hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* stats, float eps, hipStream_t s, int f16) {
     if (dim % 4 || dim > 64 * 4 * 8) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
     const dim3 grid(ceil_div(rows, 4)), block(256);
     const int vpl = ceil_div(dim / 4, 64);
-#define IVIT_RS(V) hipLaunchKernelGGL(ivit_row_stats<V>, grid, block, 0, s, x, ldx, rows, dim, xb, ldxb, stats, eps)
+#define IVIT_RS(V) hipLaunchKernelGGL(ivit_row_stats<V>, grid, block, 0, s, x, ldx, rows, dim, xb, ldxb, stats, eps, f16)
     if (vpl <= 1) IVIT_RS(1);
     else if (vpl <= 2) IVIT_RS(2);
     else if (vpl <= 3) IVIT_RS(3);
@@ -404,7 +409,7 @@ hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, i
     return hipGetLastError();
 }
 
-__global__ void ivit_f32_to_bf16(const float* __restrict__ in, int ldi, bf16_t* __restrict__ out, int ldo, int rows, int cols) {
+__global__ void ivit_f32_to_bf16(const float* __restrict__ in, int ldi, bf16_t* __restrict__ out, int ldo, int rows, int cols, int f16) {
     const int c4 = ldo >> 2;   // output is written over the full padded width
     const int64_t total = (int64_t)rows * c4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -413,28 +418,28 @@ __global__ void ivit_f32_to_bf16(const float* __restrict__ in, int ldi, bf16_t* 
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (c + e < cols) ? in[r * ldi + c + e] : 0.f;
-        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        u32x2 pk = {pack16x2(f16, v[0], v[1]), pack16x2(f16, v[2], v[3])};
         *reinterpret_cast<u32x2*>(out + r * ldo + c) = pk;
     }
 }
 
-hipError_t launch_f32_to_bf16(const float* in, int ldi, bf16_t* out, int ldo, int rows, int cols, hipStream_t s) {
+hipError_t launch_f32_to_bf16(const float* in, int ldi, bf16_t* out, int ldo, int rows, int cols, hipStream_t s, int f16) {
     if (ldo % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ivit_f32_to_bf16, dim3(ew_grid((int64_t)rows * ldo / 4)), dim3(EW_THREADS), 0, s, in, ldi, out, ldo, rows, cols);
+    hipLaunchKernelGGL(ivit_f32_to_bf16, dim3(ew_grid((int64_t)rows * ldo / 4)), dim3(EW_THREADS), 0, s, in, ldi, out, ldo, rows, cols, f16);
     return hipGetLastError();
 }
 
-__global__ void ivit_bf16_to_f32(const bf16_t* __restrict__ in, int ldi, float* __restrict__ out, int rows, int cols) {
+__global__ void ivit_bf16_to_f32(const bf16_t* __restrict__ in, int ldi, float* __restrict__ out, int rows, int cols, int f16) {
     const int64_t total = (int64_t)rows * cols;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % cols);
         const int64_t r = i / cols;
-        out[i] = bf2f(in[r * ldi + c]);
+        out[i] = dec16(f16, in[r * ldi + c]);
     }
 }
 
-hipError_t launch_bf16_to_f32(const bf16_t* in, int ldi, float* out, int rows, int cols, hipStream_t s) {
-    hipLaunchKernelGGL(ivit_bf16_to_f32, dim3(ew_grid((int64_t)rows * cols)), dim3(EW_THREADS), 0, s, in, ldi, out, rows, cols);
+hipError_t launch_bf16_to_f32(const bf16_t* in, int ldi, float* out, int rows, int cols, hipStream_t s, int f16) {
+    hipLaunchKernelGGL(ivit_bf16_to_f32, dim3(ew_grid((int64_t)rows * cols)), dim3(EW_THREADS), 0, s, in, ldi, out, rows, cols, f16);
     return hipGetLastError();
 }
 

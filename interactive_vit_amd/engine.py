@@ -38,7 +38,7 @@ class IvitConfigC(ctypes.Structure):
 
 
 ABI_VERSION = 6
-PRECISIONS = {"bf16": 0, "fp8": 1}
+PRECISIONS = {"bf16": 0, "fp8": 1, "f16": 2}
 
 
 _lib = None

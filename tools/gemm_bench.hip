@@ -220,20 +220,34 @@ int main(int argc, char** argv) {
             CK(hipDeviceSynchronize());
             std::vector<unsigned long long> hs((size_t)256 * 128);
             CK(hipMemcpy(hs.data(), dstamps, hs.size() * 8, hipMemcpyDeviceToHost));
-            const char* names[9] = {"SR0 reads issue", "barrier 1", "M0 (16 MFMA)", "barrier 2", "SR1 reads + DMA issue", "vmcnt wait", "barrier 3", "M1 (16 MFMA)", "barrier 4"};
+            {   // block -> XCD placement: the persistent walk assumes blocks b and b + 8 share an XCD
+                int agree = 0, seen = 0, per_xcd[16] = {0};
+                int first_xcd_of_class[8]; for (int i = 0; i < 8; ++i) first_xcd_of_class[i] = -1;
+                for (int b = 0; b < 256; ++b) {
+                    const int x = (int)hs[(size_t)b * 128 + 15] - 1;
+                    if (x < 0) continue;
+                    ++seen; ++per_xcd[x];
+                    if (first_xcd_of_class[b & 7] < 0) first_xcd_of_class[b & 7] = x;
+                    if (first_xcd_of_class[b & 7] == x) ++agree;
+                }
+                printf("   block placement: %d blocks, %d on the XCD of their (blockIdx %% 8) class; per XCD:", seen, agree);
+                for (int i = 0; i < 8; ++i) printf(" %d", per_xcd[i]);
+                printf("\n");
+            }
+            const char* names[9] = {"SR: DMA issue + 16 reads (+ loads)", "counted wait", "barrier 1", "M: 32 MFMA", "barrier 2", "-", "-", "-", "-"};   // a fat K-step (stamps 0..5)
             for (int grp = 0; grp < 2; ++grp) {
                 double seg[9] = {0}; int cnt = 0;
                 for (int b = 0; b < 256; ++b)
                     for (int w = grp * 4; w < grp * 4 + 4; ++w) {
                         const unsigned long long* t = &hs[(size_t)b * 128 + w * 16];
-                        if (!t[0] || !t[9]) continue;
+                        if (!t[0] || !t[5]) continue;
                         ++cnt;
-                        for (int k = 0; k < 9; ++k) seg[k] += (double)(t[k + 1] - t[k]);
+                        for (int k = 0; k < 5; ++k) seg[k] += (double)(t[k + 1] - t[k]);
                     }
                 if (!cnt) continue;
-                double tot = 0; for (int k = 0; k < 9; ++k) tot += seg[k] / cnt;
-                printf("   PE K-step stamps, waves %d-%d (%d waves), shader cycles: total %.0f |", grp * 4, grp * 4 + 3, cnt, tot);
-                for (int k = 0; k < 9; ++k) printf(" %s %.0f |", names[k], seg[k] / cnt);
+                double tot = 0; for (int k = 0; k < 5; ++k) tot += seg[k] / cnt;
+                printf("   PE fat K-step stamps, waves %d-%d (%d waves), shader cycles: total %.0f |", grp * 4, grp * 4 + 3, cnt, tot);
+                for (int k = 0; k < 5; ++k) printf(" %s %.0f |", names[k], seg[k] / cnt);
                 printf("\n");
             }
         } else if (stamp_variant == GEMM_TILE_128 || stamp_variant == GEMM_TILE_160) {   // gemm_body: per-CU timelines (who overlaps whom)
