@@ -126,6 +126,16 @@ int ivit_forward_host_chained(ivit_engine* e, int stage_begin, int stage_end, in
                               const float* in, float* out, int64_t out_capacity,
                               uint64_t in_token, uint64_t* out_token);
 
+/* Asynchronous form of ivit_forward_host_chained (Response collects every node's output only at the END of
+ * the request, main/message.py:77-83): the call enqueues upload (or takes the resident copy), kernels and the D2H copy of the
+ * result into `out` - which must be page-locked host memory that stays alive - and returns WITHOUT waiting; *ticket names the
+ * call.  `out` may be read only after ivit_host_wait(e, ticket) (or after the wait for any LATER ticket of this engine: host
+ * calls complete in order).  So node k's copy runs behind node k+1's kernels, and one wait at the end of a chain covers it. */
+int ivit_forward_host_async(ivit_engine* e, int stage_begin, int stage_end, int batch,
+                            const float* in, float* out, int64_t out_capacity,
+                            uint64_t in_token, uint64_t* out_token, uint64_t* ticket);
+int ivit_host_wait(ivit_engine* e, uint64_t ticket);
+
 /* The `<model>:preprocess` node: what the reference's model plugin does to a raw image with its weights'
  * preset (static/models/vgg16.py:40-42, `weights.transforms()`): `in` is [batch,3,height,width] f32 in
  * [0,1], any size; the shorter side is resized to image*256/224 (antialiased bilinear, ATen's

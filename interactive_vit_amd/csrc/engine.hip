@@ -176,6 +176,16 @@ struct ivit_engine {
     // chained host calls: the f32 output of the last host call stays in ext_out; a call that presents that
     // call's token takes it as its input (the two ext buffers swap roles) instead of uploading it again
     float* ext_buf0 = nullptr;
+    // asynchronous host calls (ivit_forward_host_async): an event per call, recorded behind its D2H copy
+    static constexpr int DONE_RING = 64;
+    hipEvent_t ev_done[DONE_RING] = {};
+    uint64_t done_counter = 0;
+    // the D2H copy of a host call runs on its own stream (copy engine) behind an event, so that the next node's kernels do
+    // not queue behind it; ev_buf[i] = the last copy that READ ext buffer i has finished (a later call that overwrites
+    // that buffer makes its stream wait for it)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_kernels = nullptr, ev_buf[2] = {nullptr, nullptr};
+    bool buf_copy_pending[2] = {false, false};
     uint64_t resident_token = 0, token_counter = 0;
     int64_t resident_elems = 0;
 
@@ -285,6 +295,12 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         }
         if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_ws, hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("event creation failed"); }
+        for (int i = 0; i < ivit_engine::DONE_RING; ++i)
+            if (hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("event creation failed"); }
+        if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_kernels, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_buf[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_buf[1], hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("copy stream / event creation failed"); }
     }
     chk(alloc_matrix(e, &e->w_patch, D, e->K));
     chk(alloc_vec(e, &e->b_patch, D));
@@ -364,6 +380,10 @@ extern "C" void ivit_destroy(ivit_engine* e) {
         if (e->aux_stream[i]) (void)hipStreamDestroy(e->aux_stream[i]);
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
     }
+    for (int i = 0; i < ivit_engine::DONE_RING; ++i) if (e->ev_done[i]) (void)hipEventDestroy(e->ev_done[i]);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->ev_kernels) (void)hipEventDestroy(e->ev_kernels);
+    for (int i = 0; i < 2; ++i) if (e->ev_buf[i]) (void)hipEventDestroy(e->ev_buf[i]);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_ws) (void)hipEventDestroy(e->ev_ws);
     delete e;
@@ -813,8 +833,26 @@ extern "C" int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_en
     return rc;
 }
 
+// the ext buffer `buf` is about to be overwritten on stream st: wait for the D2H copy that may still be reading it
+static int ext_buffer_writable(ivit_engine* e, const float* buf, hipStream_t st) {
+    const int i = (buf == e->ext_buf0) ? 0 : 1;
+    if (e->buf_copy_pending[i]) { HIP_TRY(hipStreamWaitEvent(st, e->ev_buf[i], 0)); e->buf_copy_pending[i] = false; }
+    return 0;
+}
+
+// D2H copy of `n` floats of ext buffer `src` into `out` on the copy stream, behind everything enqueued on st so far
+static int copy_out_async(ivit_engine* e, float* out, const float* src, int64_t n, hipStream_t st) {
+    HIP_TRY(hipEventRecord(e->ev_kernels, st));
+    HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->ev_kernels, 0));
+    HIP_TRY(hipMemcpyAsync(out, src, (size_t)n * 4, hipMemcpyDeviceToHost, e->copy_stream));
+    const int i = (src == e->ext_buf0) ? 0 : 1;
+    HIP_TRY(hipEventRecord(e->ev_buf[i], e->copy_stream));
+    e->buf_copy_pending[i] = true;
+    return 0;
+}
+
 static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int batch, const float* in, float* out,
-                             int64_t out_capacity, uint64_t in_token, uint64_t* out_token) {
+                             int64_t out_capacity, uint64_t in_token, uint64_t* out_token, uint64_t* ticket = nullptr) {
     if (check_range(e, stage_begin, stage_end, batch)) return 1;
     if (!in || !out) return fail("ivit_forward_host: null buffer");
     const int64_t n_in = shape_elems(&e->cfg, stage_begin, 0) * batch;
@@ -827,8 +865,10 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
     if (in_token != 0 && in_token == e->resident_token && n_in == e->resident_elems) {
         std::swap(e->ext_in, e->ext_out);   // the previous call's output is this call's input: no upload
     } else {
+        if (ext_buffer_writable(e, e->ext_in, st)) return 1;
         HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
     }
+    if (ext_buffer_writable(e, e->ext_out, st)) return 1;   // the copy of two calls ago may still be reading it
     e->resident_token = 0;                  // ext_out is about to be overwritten
     const int L = e->cfg.layers;
     const bool many_launches = (stage_end - stage_begin) > 1 || (stage_begin >= ST_LAYER0 && stage_begin < ST_LAYER0 + L);
@@ -843,9 +883,10 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
             // hipFuncSetAttribute outside of a capture), then capture the same launch sequence on the
             // engine's own stream for the following requests (nothing in it syncs or allocates)
             if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
-            HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+            if (copy_out_async(e, out, e->ext_out, n_out, st)) return 1;
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipStreamSynchronize(e->copy_stream));
             // the capture replays the launches on the same buffers; an encoder layer updates its input
             // in place only after copying it to the workspace, so ext_in is still intact
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -865,9 +906,15 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
     } else {
         if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
     }
-    if (!done) HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+    if (!done && copy_out_async(e, out, e->ext_out, n_out, st)) return 1;
     if (ws_release(e, st)) return 1;
-    if (!done) HIP_TRY(hipStreamSynchronize(st));
+    if (ticket) {   // asynchronous form: the caller waits for this call's D2H copy through ivit_host_wait(ticket)
+        const uint64_t tk = ++e->done_counter;
+        HIP_TRY(hipEventRecord(e->ev_done[tk % ivit_engine::DONE_RING], e->copy_stream));
+        *ticket = tk;
+    } else if (!done) {
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    }
     e->resident_token = ++e->token_counter;
     e->resident_elems = n_out;
     if (out_token) *out_token = e->resident_token;
@@ -882,6 +929,27 @@ extern "C" int ivit_forward_host(ivit_engine* e, int stage_begin, int stage_end,
 extern "C" int ivit_forward_host_chained(ivit_engine* e, int stage_begin, int stage_end, int batch, const float* in, float* out,
                                          int64_t out_capacity, uint64_t in_token, uint64_t* out_token) {
     return forward_host_impl(e, stage_begin, stage_end, batch, in, out, out_capacity, in_token, out_token);
+}
+
+extern "C" int ivit_forward_host_async(ivit_engine* e, int stage_begin, int stage_end, int batch, const float* in, float* out,
+                                       int64_t out_capacity, uint64_t in_token, uint64_t* out_token, uint64_t* ticket) {
+    if (!ticket) return fail("ivit_forward_host_async: ticket is null");
+    return forward_host_impl(e, stage_begin, stage_end, batch, in, out, out_capacity, in_token, out_token, ticket);
+}
+
+extern "C" int ivit_host_wait(ivit_engine* e, uint64_t ticket) {
+    if (!e) return fail("ivit_host_wait: null engine");
+    hipEvent_t ev = nullptr;
+    bool stale = false;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (ticket == 0 || ticket > e->done_counter) return fail("ivit_host_wait: ticket %llu was never issued", (unsigned long long)ticket);
+        stale = ticket + ivit_engine::DONE_RING <= e->done_counter;   // its event was re-used: every call issued since is behind it on the same stream
+        ev = e->ev_done[(stale ? e->done_counter : ticket) % ivit_engine::DONE_RING];
+    }
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipEventSynchronize(ev));
+    return 0;
 }
 
 // caller holds e->mu and has set the device
@@ -933,6 +1001,7 @@ extern "C" int ivit_attention_map_host(ivit_engine* e, int layer, int batch, con
         e->map_bytes = need;
     }
     if (ws_acquire(e, st)) return 1;
+    if (ext_buffer_writable(e, e->ext_in, st)) return 1;
     HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
     if (attention_map_locked(e, layer, batch, e->ext_in, e->map_buf, st)) return 1;
     HIP_TRY(hipMemcpyAsync(out, e->map_buf, need, hipMemcpyDeviceToHost, st));
@@ -975,6 +1044,7 @@ extern "C" int ivit_preprocess_host(ivit_engine* e, int batch, const float* in, 
     }
     if (ws_acquire(e, st)) return 1;
     e->resident_token = 0;
+    if (ext_buffer_writable(e, e->ext_out, st)) return 1;
     HIP_TRY(hipMemcpyAsync(e->pre_buf, in, need, hipMemcpyHostToDevice, st));
     HIP_TRY(launch_preprocess(e->pre_buf, height, width, e->ext_out, batch, S, preprocess_resize(e), st));
     HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));

@@ -27,6 +27,7 @@ ABI_SYMBOLS = (
     "ivit_fp8_calibrate", "ivit_fp8_scales", "ivit_debug_unfold", "ivit_profile_enable",
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
     "ivit_profile_kernel_count", "ivit_profile_kernel_read", "ivit_debug_layer_tap", "ivit_debug_weight_fp8", "ivit_ln_fold_calibrate",
+    "ivit_forward_host_async", "ivit_host_wait",
 )
 
 
@@ -78,6 +79,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_ln_fold.restype = c_i
         lib.ivit_forward_host.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64]
         lib.ivit_forward_host_chained.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        lib.ivit_forward_host_async.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+                                                ctypes.POINTER(ctypes.c_uint64)]
+        lib.ivit_host_wait.argtypes = [c_p, ctypes.c_uint64]
         lib.ivit_preprocess_host.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_i64, ctypes.POINTER(ctypes.c_uint64)]
         lib.ivit_preprocess.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_p]
         lib.ivit_forward_device.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
@@ -102,6 +106,51 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         if path is None:
             _lib = lib
         return lib
+
+
+class PendingTensor(torch.Tensor):
+    """A CPU f32 tensor in page-locked memory whose bytes the engine's D2H copy may still be writing
+    (include/ivit.h: ivit_forward_host_async).  Any torch operation on it - ``numpy()``, arithmetic, indexing, ``shape`` -
+    first waits for that copy (once), then runs on the plain tensor; the engine itself recognises it and continues from
+    the device-resident copy without touching the host bytes.  So in a chain of nodes (Context.compute hands node k's
+    output to node k+1 by reference and Response reads all outputs only at the end, reference main/context.py:143-147,
+    main/message.py:77-83) the copy of node k runs behind the kernels of node k+1."""
+
+    @staticmethod
+    def wrap(data: torch.Tensor, engine: "Engine", ticket: int) -> "PendingTensor":
+        t = torch.Tensor._make_subclass(PendingTensor, data)
+        t._ivit_engine = weakref.ref(engine)
+        t._ivit_ticket = int(ticket)
+        t._ivit_done = False
+        t._ivit_ptr = data.data_ptr()
+        t._ivit_shape = tuple(data.shape)
+        return t
+
+    def _ivit_wait(self) -> None:
+        if not getattr(self, "_ivit_done", True):
+            eng = self._ivit_engine()
+            if eng is not None and eng._h is not None and eng._h.value:
+                eng._check(eng.lib.ivit_host_wait(eng._h, ctypes.c_uint64(self._ivit_ticket)))
+            self._ivit_done = True
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+
+        def sync(a):
+            if isinstance(a, PendingTensor):
+                a._ivit_wait()
+            elif isinstance(a, (list, tuple)):
+                for b in a:
+                    sync(b)
+            elif isinstance(a, dict):
+                for b in a.values():
+                    sync(b)
+
+        sync(args)
+        sync(kwargs)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
 
 
 class EngineError(Exception):
@@ -145,6 +194,8 @@ class Engine:
         self.cfg = cfg
         self.ln_fold = False      # set after creation: does the engine fold LayerNorm into the next GEMM (ivit_ln_fold)
         self._pin = os.environ.get("IVIT_PINNED_OUTPUTS", "1") != "0"
+        # host path: return lazily-synchronised tensors (the D2H copy of a node overlaps the next node's kernels)
+        self._async = self._pin and os.environ.get("IVIT_ASYNC_OUTPUTS", "1") != "0"
         self._last_out = None     # (weakref to the last host-path output, its version counter, its residency token)
         self.device = int(device)
         self.max_batch = int(max_batch)
@@ -195,10 +246,11 @@ class Engine:
 
     def _split_batch(self, x: torch.Tensor, stage: int) -> Tuple[int, bool]:
         want = self.in_shape(stage)
-        if tuple(x.shape) == want:
+        shape = x._ivit_shape if isinstance(x, PendingTensor) else tuple(x.shape)   # (shape of a pending tensor: no wait)
+        if shape == want:
             return 1, False
-        if x.dim() == len(want) + 1 and tuple(x.shape[1:]) == want:
-            return int(x.shape[0]), True
+        if len(shape) == len(want) + 1 and shape[1:] == want:
+            return int(shape[0]), True
         raise EngineError(f"{self.cfg.name}:{self.stages[stage]} expects input {list(want)} "
                           f"(optionally with a leading batch axis), got {list(x.shape)}")
 
@@ -209,19 +261,33 @@ class Engine:
         batch, batched = self._split_batch(x, begin)
         oshape = self.out_shape(end - 1)
         full = ((batch,) + oshape) if batched else oshape
-        if x.device.type == "cpu":
+        if isinstance(x, PendingTensor) or x.device.type == "cpu":
             # node chains: when `x` is the very tensor the previous host call returned (Context.compute
             # hands outputs on by reference) and nobody wrote to it since, its device-resident copy is
             # consumed instead of uploading it again (include/ivit.h: ivit_forward_host_chained)
-            token = 0
-            last = self._last_out
-            if last is not None and last[0]() is x and x._version == last[1]:
-                token = last[2]
-            xin = x.detach().to(torch.float32).contiguous()
+            with torch._C.DisableTorchFunctionSubclass():      # no torch call below may wait for a pending copy
+                token = 0
+                last = self._last_out
+                if last is not None and last[0]() is x and x._version == last[1]:
+                    token = last[2]
+                xin = x.detach().to(torch.float32).contiguous()   # a PendingTensor is f32 and contiguous: a view, no bytes read
+                in_ptr = xin.data_ptr()
             # page-locked result buffer (torch caches the blocks): the D2H copy runs at DMA speed
             out = torch.empty(full, dtype=torch.float32, pin_memory=self._pin)
             new_token = ctypes.c_uint64(0)
-            self._check(self.lib.ivit_forward_host_chained(self._h, begin, end, batch, ctypes.c_void_p(xin.data_ptr()),
+            if self._async:
+                # If the token is stale the library uploads `in` on its own stream, i.e. BEHIND the copy that may still be
+                # filling a pending `x` (page-locked, stream-ordered) - correct without a host-side wait.  A pageable or
+                # converted input was produced by a torch operation, which has waited already.
+                ticket = ctypes.c_uint64(0)
+                self._check(self.lib.ivit_forward_host_async(self._h, begin, end, batch, ctypes.c_void_p(in_ptr),
+                                                             ctypes.c_void_p(out.data_ptr()), out.numel(),
+                                                             ctypes.c_uint64(token), ctypes.byref(new_token), ctypes.byref(ticket)))
+                res = PendingTensor.wrap(out, self, ticket.value)
+                with torch._C.DisableTorchFunctionSubclass():
+                    self._last_out = (weakref.ref(res), res._version, new_token.value)
+                return res
+            self._check(self.lib.ivit_forward_host_chained(self._h, begin, end, batch, ctypes.c_void_p(in_ptr),
                                                            ctypes.c_void_p(out.data_ptr()), out.numel(),
                                                            ctypes.c_uint64(token), ctypes.byref(new_token)))
             self._last_out = (weakref.ref(out), out._version, new_token.value)
