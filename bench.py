@@ -272,6 +272,16 @@ def main():
     x = synthetic_images(B, cfg, seed=1234 + rank, device=f"cuda:{local_rank}")   # generated on device
     if args.precision == "fp8":
         eng.calibrate_fp8(x)        # static activation scales + weight quantisation, outside the timed region
+    # the ONE collective of the path is issued by the engine itself through RCCL (include/ivit.h: ivit_allgather_cls); torch's
+    # process group only carries the communicator id, the barriers and the max-over-ranks of the timing (IVIT_GATHER=torch
+    # routes the all-gather through torch.distributed instead: the round-1 path, kept for A/B)
+    engine_gather = use_dist and os.environ.get("IVIT_GATHER", "engine") != "torch"
+    if engine_gather:
+        def bcast(b):
+            box = [b]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        eng.comm_init(rank, world, bcast)
     ns = len(eng.stages)
     width = cfg.classes + cfg.dim
     # [logits | cls features] of this rank and the gathered block of the whole batch, double buffered so that
@@ -299,7 +309,9 @@ def main():
                 pending[k].wait()                               # the collective that last used this buffer pair
             packed[k][:, :cfg.classes].copy_(logits)
             packed[k][:, cfg.classes:].copy_(clsf)
-            if overlap:
+            if engine_gather:
+                eng.allgather(packed[k], gathered[k], stream.cuda_stream)                             # the ONE collective of the path
+            elif overlap:
                 pending[k] = all_gather_outputs(packed[k], total, out=gathered[k], async_op=True)   # the ONE collective of the path
             else:
                 all_gather_outputs(packed[k], total, out=gathered[k])
@@ -485,7 +497,8 @@ def main():
                                    "f32 images resident in HBM -> f32 logits + class-token features"
                                    + (", one RCCL all-gather per step" if use_dist else ""),
                        "baseline_config": args.config or (2 if (args.model, B, args.precision) == CONFIGS[2] else None),
-                       "collective": "all_gather_into_tensor over nccl (RCCL), 1 per step" if use_dist else None,
+                       "collective": ("ncclAllGather issued by the engine (ivit_allgather_cls, RCCL), 1 per step" if engine_gather
+                                      else "all_gather_into_tensor over nccl (RCCL), 1 per step") if use_dist else None,
                        "collective_overlap": ("async on RCCL's stream behind the next step's compute, drained inside the timed region" if overlap else "in line") if use_dist else None,
                        "batch_per_gpu": B, "global_batch": total, "tokens": cfg.tokens,
                        "gflop_per_image": round(flops_img / 1e9, 3), "parallelism": f"dp{world}",

@@ -177,6 +177,18 @@ int ivit_fp8_scales(ivit_engine* e, float* out, int capacity);
  * normalise != 0 applies the transform first (the fused path), 0 unfolds the input as is. */
 int ivit_debug_unfold(ivit_engine* e, int batch, const void* in, void* out, int normalise, void* stream);
 
+/* Multi-GPU (the reference has no counterpart): images shard by batch over the GPUs of one node, one
+ * process and one engine per GPU, weights replicated; the ONLY data-path collective is one all-gather per batch of every
+ * rank's packed [b_local, classes + D] f32 block (logits | class-token features), issued by the engine through RCCL over
+ * xGMI on the caller's stream.  librccl.so is loaded on demand by these entries.
+ *   ivit_comm_unique_id: rank 0 creates the 128-byte id and the host distributes it to the other ranks (any channel);
+ *   ivit_comm_init:      every rank binds its engine to the communicator (collective: all ranks must call it);
+ *   ivit_allgather_cls:  recv[r * floats_per_rank ...] = rank r's send block, equal block sizes, enqueued on `stream`,
+ *                        no synchronisation.  The communicator is destroyed with the engine. */
+int ivit_comm_unique_id(void* id128);
+int ivit_comm_init(ivit_engine* e, const void* id128, int rank, int world);
+int ivit_allgather_cls(ivit_engine* e, const void* send, void* recv, int64_t floats_per_rank, void* stream);
+
 /* Inspection entries used by the per-GEMM parity tests.  An encoder layer is seven steps: 1 LayerNorm 1 (with the
  * LayerNorm fold: the 16-bit operand copy of x the QKV GEMM consumes), 2 QKV projection, 3 attention, 4 out-projection
  * (+ residual), 5 LayerNorm 2 (fold: nothing new - the copy the out-projection left), 6 MLP up (+ GELU), 7 MLP down

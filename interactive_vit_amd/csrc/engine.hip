@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -42,6 +43,45 @@ extern "C" const char* ivit_build_info(void) {
     return "libivit gfx950 (MI355X/CDNA4) bf16/f16/fp8-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_{128x128,160x128,256x256}x64, ivit_gemm_fp8_{128x128,160x128,256x256}x128, ivit_attention_bf16, "
            "ivit_layernorm, ivit_unfold, ivit_tokens, ivit_transform";
 }
+
+// ------------------------------------------------------------------------------------ RCCL (loaded on demand)
+// The one collective of the path (batch shards over the GPUs of a node, ONE all-gather of the [b, classes + D]
+// output block per step) is issued from the engine on the caller's stream.  librccl.so is dlopen-ed by ivit_comm_init, so
+// single-GPU users never load it; the five entry points are bound by name (rccl.h: ncclGetUniqueId, ncclCommInitRank,
+// ncclAllGather, ncclCommDestroy, ncclGetErrorString).
+namespace {
+struct RcclUniqueId { char internal[128]; };            // NCCL_UNIQUE_ID_BYTES
+typedef void* RcclComm;
+struct Rccl {
+    void* lib = nullptr;
+    int (*get_unique_id)(RcclUniqueId*) = nullptr;
+    int (*comm_init_rank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+    int (*all_gather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*comm_destroy)(RcclComm) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+const int kRcclFloat32 = 7;                              // ncclFloat32 (rccl.h ncclDataType_t)
+
+int rccl_load(std::string* why) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) { *why = std::string("librccl.so not found: ") + dlerror(); return 1; }
+    Rccl r; r.lib = lib;
+    r.get_unique_id = (int (*)(RcclUniqueId*))dlsym(lib, "ncclGetUniqueId");
+    r.comm_init_rank = (int (*)(RcclComm*, int, RcclUniqueId, int))dlsym(lib, "ncclCommInitRank");
+    r.all_gather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))dlsym(lib, "ncclAllGather");
+    r.comm_destroy = (int (*)(RcclComm))dlsym(lib, "ncclCommDestroy");
+    r.error_string = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy || !r.error_string) { *why = "librccl.so lacks an expected entry point"; return 1; }
+    g_rccl = r;
+    return 0;
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------ stages
 enum { ST_TRANSFORM = 0, ST_CONV = 1, ST_TOKENS = 2, ST_LAYER0 = 3 };
@@ -188,6 +228,10 @@ struct ivit_engine {
     bool buf_copy_pending[2] = {false, false};
     uint64_t resident_token = 0, token_counter = 0;
     int64_t resident_elems = 0;
+
+    // RCCL communicator of this engine's rank (ivit_comm_init); nullptr = single GPU
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
 
     // profiling
     bool prof_on = false;
@@ -368,6 +412,7 @@ extern "C" void ivit_destroy(ivit_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
+    if (e->comm && g_rccl.comm_destroy) { (void)g_rccl.comm_destroy(e->comm); e->comm = nullptr; }
     for (int c = 0; c < PC_COUNT; ++c)
         for (auto& sp : e->spans[c]) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
@@ -1208,6 +1253,46 @@ extern "C" int ivit_debug_weight_fp8(ivit_engine* e, int layer, int which, void*
     if (rows) *rows = q.rows;
     if (cols) *cols = q.cols;
     if (ld) *ld = q.ld;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ multi-GPU: the one all-gather
+extern "C" int ivit_comm_unique_id(void* id128) {
+    if (!id128) return fail("ivit_comm_unique_id: null buffer");
+    std::string why;
+    if (rccl_load(&why)) return fail("ivit_comm_unique_id: %s", why.c_str());
+    RcclUniqueId id;
+    const int rc = g_rccl.get_unique_id(&id);
+    if (rc != 0) return fail("ncclGetUniqueId failed: %s", g_rccl.error_string(rc));
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int ivit_comm_init(ivit_engine* e, const void* id128, int rank, int world) {
+    if (!e || !id128) return fail("ivit_comm_init: null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail("ivit_comm_init: rank %d outside a world of %d", rank, world);
+    std::string why;
+    if (rccl_load(&why)) return fail("ivit_comm_init: %s", why.c_str());
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->comm) return fail("ivit_comm_init: this engine already has a communicator");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    RcclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    RcclComm comm = nullptr;
+    const int rc = g_rccl.comm_init_rank(&comm, world, id, rank);
+    if (rc != 0) return fail("ncclCommInitRank failed: %s", g_rccl.error_string(rc));
+    e->comm = comm; e->comm_rank = rank; e->comm_world = world;
+    return 0;
+}
+
+extern "C" int ivit_allgather_cls(ivit_engine* e, const void* send, void* recv, int64_t floats_per_rank, void* stream) {
+    if (!e || !send || !recv) return fail("ivit_allgather_cls: null argument");
+    if (floats_per_rank <= 0) return fail("ivit_allgather_cls: nothing to gather");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->comm) return fail("ivit_allgather_cls: no communicator (call ivit_comm_init on every rank first)");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int rc = g_rccl.all_gather(send, recv, (size_t)floats_per_rank, kRcclFloat32, e->comm, (hipStream_t)stream);
+    if (rc != 0) return fail("ncclAllGather failed: %s", g_rccl.error_string(rc));
     return 0;
 }
 

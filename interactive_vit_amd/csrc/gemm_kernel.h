@@ -16,6 +16,7 @@
 // (cdna_hip_programming.md T2 / rule 21).
 #pragma once
 #include "kernels.h"
+#include <type_traits>
 
 namespace ivit {
 
@@ -349,7 +350,7 @@ __device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 
 // per-64-column (sum, M2) pairs a residual GEMM left (ln_part), folded in slot order with Chan's formula - exact
 // two-pass statistics, the same bits whatever tile shape wrote the pairs and whichever column tile folds them.
 template <class T>
-__device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float2* tile_stats) {
+__device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float2* tile_stats, const float4* first = nullptr) {
     for (int r = threadIdx.x; r < T::BM; r += T::THREADS) {
         const int m = min(m0 + r, p.M - 1);     // rows past M: a valid row's statistics (their outputs are never stored)
         float2 st;
@@ -368,7 +369,7 @@ __device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float
                 if (s0 >= nslots) break;                      // uniform
                 float4 raw[6];
 #pragma unroll
-                for (int l = 0; l < 6; ++l) raw[l] = pr[min((s0 >> 1) + l, GEMM_LN_SLOTS / 2 - 1)];
+                for (int l = 0; l < 6; ++l) raw[l] = (s0 == 0 && first) ? first[l] : pr[min((s0 >> 1) + l, GEMM_LN_SLOTS / 2 - 1)];   // the first 12 slots may have been loaded ahead (ln_tile_stats_prefetch)
 #pragma unroll
                 for (int q = 0; q < 12; ++q) {
                     constexpr float inv64 = 1.0f / 64.0f;
@@ -391,6 +392,19 @@ __device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float
         }
         tile_stats[r] = st;
     }
+}
+
+// The first 12 slots of this thread's row, loaded at the very start of the kernel (one row per thread: BM <= THREADS).  The
+// loads are in flight together with the first operand DMA and are retired by the K loop's first wait anyway; the fold itself
+// (ln_tile_stats with `first`) then runs after that wait.  Folding before the loop cost every tile 1.6 us of exposed load
+// latency (per-block stamps, tools/gemm_bench): 6-7 us per MLP-up launch.
+template <class T>
+__device__ __forceinline__ void ln_tile_stats_prefetch(const GemmParams& p, int m0, float4 (&first)[6]) {
+    static_assert(T::BM <= T::THREADS, "one row per thread");
+    const int m = min(m0 + min((int)threadIdx.x, T::BM - 1), p.M - 1);
+    const float4* pr = reinterpret_cast<const float4*>(p.ln_part + (size_t)m * GEMM_LN_SLOTS);
+#pragma unroll
+    for (int l = 0; l < 6; ++l) first[l] = pr[l];
 }
 
 // EK = 0: the classic epilogues (kind chosen at run time); 1: EPI_BIAS_RESID_STATS; 2: EPI_LNFOLD_*.
@@ -484,18 +498,29 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, 0, smem, wave, lane);
     stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, 0, smem + T::A_BYTES, wave, lane);
     float2* tile_stats = reinterpret_cast<float2*>(smem + T::LDS_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
-    if (EK == 2) ln_tile_stats<T>(p, m0, tile_stats);                      // visible to every wave after the K loop's barriers
+    float4 ln_first[6];
+    const bool ln_deferred = EK == 2 && !p.ln_stats && nt >= 2;             // fold inside the K loop (behind its first wait); else here
+    if (EK == 2) {
+        if (ln_deferred) ln_tile_stats_prefetch<T>(p, m0, ln_first);
+        else ln_tile_stats<T>(p, m0, tile_stats);                          // visible to every wave after the K loop's barriers
+    }
     IVIT_BODY_STAMP(1);
 
     const int fr = lane & 15;   // fragment row (m for the A^T operand, n for the W operand)
     const int fq = lane >> 4;   // 16-B k-chunk inside a 32-deep MFMA step
 
-    for (int t = 0; t < nt; ++t) {
+    // one K-tile; FOLD (first iteration of the LayerNorm-fold kernels only, a separate copy of the body so that the loop proper
+    // carries neither the branch nor the prefetched registers): fold the prefetched statistics pairs right after the wait
+    auto ktile = [&](int t, auto fold_tag) {
+        constexpr bool FOLD = decltype(fold_tag)::value;
         // tile t has landed (every wave drains its own DMA, then the barrier publishes it); every
         // wave is also past its reads of the buffer that tile t+1 is about to overwrite
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         char* cur = smem + (t & 1) * T::STAGE_BYTES;
+        // the prefetched statistics pairs have landed (the wait above); fold them BEFORE the next DMA is issued (a use of an
+        // ordinary load behind in-flight LDS-DMA makes hipcc wait for all of it); published by the next iteration's barrier
+        if (FOLD) ln_tile_stats<T>(p, m0, tile_stats, ln_first);
         if (t + 1 < nt) {
             char* nxt = smem + ((t + 1) & 1) * T::STAGE_BYTES;
             stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, (t + 1) * 128, nxt, wave, lane);
@@ -538,7 +563,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
                 __builtin_amdgcn_s_setprio(0);
             }
         }
+    };
+    int t_first = 0;
+    if (EK == 2) {
+        if (ln_deferred) { ktile(0, std::true_type{}); t_first = 1; }
     }
+    for (int t = t_first; t < nt; ++t) ktile(t, std::false_type{});
     IVIT_BODY_STAMP(2);
     gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
     IVIT_BODY_STAMP(3);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "ivit_fp8_calibrate", "ivit_fp8_scales", "ivit_debug_unfold", "ivit_profile_enable",
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
     "ivit_profile_kernel_count", "ivit_profile_kernel_read", "ivit_debug_layer_tap", "ivit_debug_weight_fp8", "ivit_ln_fold_calibrate",
-    "ivit_forward_host_async", "ivit_host_wait",
+    "ivit_forward_host_async", "ivit_host_wait", "ivit_comm_unique_id", "ivit_comm_init", "ivit_allgather_cls",
 )
 
 
@@ -82,6 +82,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_forward_host_async.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
                                                 ctypes.POINTER(ctypes.c_uint64)]
         lib.ivit_host_wait.argtypes = [c_p, ctypes.c_uint64]
+        lib.ivit_comm_unique_id.argtypes = [c_p]
+        lib.ivit_comm_init.argtypes = [c_p, c_p, c_i, c_i]
+        lib.ivit_allgather_cls.argtypes = [c_p, c_p, c_p, c_i64, c_p]
         lib.ivit_preprocess_host.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_i64, ctypes.POINTER(ctypes.c_uint64)]
         lib.ivit_preprocess.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_p]
         lib.ivit_forward_device.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
@@ -354,6 +357,27 @@ class Engine:
         stream = torch.cuda.current_stream(x.device).cuda_stream
         self._check(self.lib.ivit_preprocess(self._h, batch, ctypes.c_void_p(xin.data_ptr()), h, w,
                                              ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
+        return out
+
+    # -- multi-GPU: the one collective of the path, issued by the engine through RCCL ----------------
+    def comm_init(self, rank: int, world: int, broadcast_bytes) -> None:
+        """Binds this engine to an RCCL communicator of `world` ranks (include/ivit.h: ivit_comm_*).  `broadcast_bytes(b)`
+        must return rank 0's bytes object on every rank (e.g. through torch.distributed's store / object broadcast)."""
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            self._check(self.lib.ivit_comm_unique_id(buf))
+        ident = broadcast_bytes(bytes(buf.raw))
+        assert len(ident) == 128
+        self._check(self.lib.ivit_comm_init(self._h, ctypes.c_char_p(ident), int(rank), int(world)))
+        self.comm_world = int(world)
+
+    def allgather(self, local: torch.Tensor, out: torch.Tensor, stream: Optional[int] = None) -> torch.Tensor:
+        """out[r * b : (r + 1) * b] = rank r's `local` ([b, width] f32, equal on every rank), enqueued on `stream`."""
+        assert local.is_cuda and out.is_cuda and local.dtype == out.dtype == torch.float32 and local.is_contiguous() and out.is_contiguous()
+        assert out.numel() == local.numel() * self.comm_world
+        st = stream if stream is not None else torch.cuda.current_stream(local.device).cuda_stream
+        self._check(self.lib.ivit_allgather_cls(self._h, ctypes.c_void_p(local.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                local.numel(), ctypes.c_void_p(st)))
         return out
 
     def ln_fold_for(self, batch: int) -> bool:

@@ -29,7 +29,7 @@ def test_bench_runs_under_torchrun_with_rccl():
     assert len(out_lines) == 1, out_lines          # RCCL's banner etc. must not reach stdout: ONE line, the result
     d = json.loads(out_lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["collective"] == "all_gather_into_tensor over nccl (RCCL), 1 per step"
+    assert d["config"]["collective"] == "ncclAllGather issued by the engine (ivit_allgather_cls, RCCL), 1 per step"
     assert d["parity"]["gathered_equals_local"] is True
 
 
