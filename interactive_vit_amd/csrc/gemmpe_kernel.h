@@ -30,6 +30,10 @@
 
 namespace ivit {
 
+#ifndef IVIT_PE_THIN
+#define IVIT_PE_THIN 0   // 1: the first four K-steps of a tile in the thin form (16-MFMA intervals, 32 fragment registers)
+#endif
+
 struct TilePE {
     static constexpr int BM = 256, BN = 128, WAVES = 8, THREADS = 512;
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
@@ -320,6 +324,27 @@ __device__ __forceinline__ void pe_kstep_fat(PeCtx& c, f32x4 (&acc)[4][4], PeSta
     c.slot = pe_next_slot(c.slot);
 }
 
+// the fat K-step that also carries two epilogue units of the previous tile in its M interval (K-steps 0..3 of a tile)
+template <class OP, bool GELU, int U0, int U1, bool VEC, int WAIT>
+__device__ __forceinline__ void pe_kstep_fat_epi(PeCtx& c, f32x4 (&acc)[4][4], const f32x4 (&prev)[4][4], int pm0, int pn0, const char* tb_prev, int n0,
+                                                 char* tb_cur) {
+    bf16x8 af0[4], wf0[4], af1[4], wf1[4];
+    pe_stage(c, pe_write_slot(c.slot));
+    if (VEC) pe_stage_vectors(c, n0, tb_cur);
+    pe_read(c, c.slot, 0, af0, wf0);
+    pe_read(c, c.slot, 1, af1, wf1);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(WAIT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (U0 >= 0) pe_epilogue_unit<OP, GELU, (U0 >= 0 ? U0 : 0)>(c, prev, pm0, pn0, tb_prev);
+    pe_mma16<OP>(acc, af0, wf0);
+    if (U1 >= 0) pe_epilogue_unit<OP, GELU, (U1 >= 0 ? U1 : 0)>(c, prev, pm0, pn0, tb_prev);
+    pe_mma16<OP>(acc, af1, wf1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    c.slot = pe_next_slot(c.slot);
+}
+
 template <class OP, bool GELU>
 __device__ __forceinline__ void gemmpe_body(const GemmParams& p, char* smem) {
     using T = TilePE;
@@ -400,6 +425,7 @@ __device__ __forceinline__ void gemmpe_body(const GemmParams& p, char* smem) {
         f32x4 ra0 = {0.f, 0.f, 0.f, 0.f}, ra1 = ra0, rb0 = ra0, rb1 = ra0;   // two chunks of statistics loads in flight (sets a / b)
 #define PE_THIN c, acc, prev, pm0, pn0, tb_prev, n0, tb_cur
 #define PE_FAT c, acc, st
+        if (IVIT_PE_THIN) {
         if (k == 0) {   // first tile of the workgroup: nothing to drain
             pe_kstep_thin<OP, GELU, -1, -1, true, 7>(PE_THIN);     // 6 + the vector DMA
             pe_kstep_thin<OP, GELU, -1, -1, false, 7>(PE_THIN);    // vector DMA + 6
@@ -412,6 +438,22 @@ __device__ __forceinline__ void gemmpe_body(const GemmParams& p, char* smem) {
             pe_kstep_thin<OP, GELU, 4, 5, false, 9>(PE_THIN);      // 2 stores, 6 + 1
             pe_kstep_thin<OP, GELU, 6, 7, false, 9>(PE_THIN);
             pe_kstep_fat<OP, 10, true, false>(PE_FAT, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);                   // K-step 4: 2 stores, 6 + 2 loads
+        }
+        } else {
+        // all K-steps fat; the first four carry two epilogue units each in their M interval (both stores after the DMA and the wait)
+        if (k == 0) {
+            pe_kstep_fat_epi<OP, GELU, -1, -1, true, 7>(PE_THIN);     // 6 + the vector DMA
+            pe_kstep_fat_epi<OP, GELU, -1, -1, false, 7>(PE_THIN);    // vector DMA + 6
+            pe_kstep_fat_epi<OP, GELU, -1, -1, false, 6>(PE_THIN);
+            pe_kstep_fat_epi<OP, GELU, -1, -1, false, 6>(PE_THIN);
+            pe_kstep_fat<OP, 8, true, false>(PE_FAT, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);                    // K-step 4: chunk 0 -> a; 6 + 2
+        } else {
+            pe_kstep_fat_epi<OP, GELU, 0, 1, true, 7>(PE_THIN);       // 6 + vector DMA
+            pe_kstep_fat_epi<OP, GELU, 2, 3, false, 9>(PE_THIN);      // vector DMA + 2 stores + 6
+            pe_kstep_fat_epi<OP, GELU, 4, 5, false, 8>(PE_THIN);      // 2 stores + 6
+            pe_kstep_fat_epi<OP, GELU, 6, 7, false, 8>(PE_THIN);
+            pe_kstep_fat<OP, 10, true, false>(PE_FAT, 0, 0, nchunks, nslots, ra0, ra1, ra0, ra1, chan);                   // K-step 4: 2 stores + 6 + 2 loads
+        }
         }
         // K-steps 5 .. 3 + nch: load chunk j + 1, fold chunk j (the wait leaves this K-step's 6 DMA and 2 loads outstanding)
         int t = 5;
