@@ -477,9 +477,18 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     IVIT_BODY_STAMP(0);
 
     int tm, tn;
-#ifdef IVIT_GEMM_ABLATIONS
+#ifdef IVIT_GEMM_ABLATIONS   // tile orders that were measured and did not pay: row bands per XCD; pairs sharing a CU's L1
     if (p.order == 1) tile_coords_banded(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
-    else
+    else if (p.order == 2) {
+        // Paired order for single-round grids of the two-workgroups-per-CU kernels (grid = 512): blocks b and b + 256 - the two
+        // workgroups a CU receives when every CU gets one block before any gets its second - take the SAME row tile and
+        // column tiles hn apart, so that the A lines one of them pulls through the CU's vector L1 could serve the other.
+        const int tiles_m = ceil_div(p.M, T::BM), hn = ceil_div(p.N, T::BN) >> 1;
+        const int first = blockIdx.x & 255, x = first & 7, j = first >> 3;
+        tm = (j / hn) * 8 + x;
+        tn = j % hn + ((blockIdx.x >> 8) ? hn : 0);
+        if (tm >= tiles_m) return;
+    } else
 #endif
     tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
     const int m0 = tm * T::BM;

@@ -167,6 +167,12 @@ static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream,
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), T::LDS_BYTES + extra_lds);
     if (e != hipSuccess) return e;
     const int tiles = ceil_div(p.M, T::BM) * ceil_div(p.N, T::BN);
+#ifdef IVIT_GEMM_ABLATIONS
+    if (p.order == 2) {   // paired order: 512 blocks (some idle), see gemm_body
+        hipLaunchKernelGGL(kernel, dim3(512), dim3(T::THREADS), T::LDS_BYTES + extra_lds, stream, p);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(kernel, dim3(tiles), dim3(T::THREADS), T::LDS_BYTES + extra_lds, stream, p);
     return hipGetLastError();
 }

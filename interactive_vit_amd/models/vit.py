@@ -168,7 +168,8 @@ class HipBackend:
 
 
 def build_plugins(ModelBase, PinoutCls, variants: Sequence[str] = ("vit_b_16",), device: int = 0,
-                  max_batch: int = 1, seed: int = 0, state_dicts: Optional[Dict[str, Dict[str, torch.Tensor]]] = None):
+                  max_batch: int = 1, seed: int = 0, state_dicts: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
+                  precision: str = "bf16"):
     """What a plugin file's ``instances()`` returns: one registered model per variant.
 
     Weights: ``state_dicts[name]`` when given (e.g. loaded from a local safetensors file with
@@ -179,7 +180,7 @@ def build_plugins(ModelBase, PinoutCls, variants: Sequence[str] = ("vit_b_16",),
     for v in variants:
         cfg = VARIANTS[v]
         sd = (state_dicts or {}).get(v) or init_weights(cfg, seed=seed, mode="spec")
-        models.append(cls(cfg, HipBackend(cfg, sd, device=device, max_batch=max_batch)))
+        models.append(cls(cfg, HipBackend(cfg, sd, device=device, max_batch=max_batch, precision=precision)))
     return models
 
 
@@ -194,4 +195,5 @@ def instances():
     variants = tuple(v for v in os.environ.get("IVIT_VARIANTS", "vit_b_16").split(",") if v)
     return build_plugins(ModelBase, PinoutCls, variants,
                          device=int(os.environ.get("IVIT_DEVICE", "0")),
-                         max_batch=int(os.environ.get("IVIT_MAX_BATCH", "1")))
+                         max_batch=int(os.environ.get("IVIT_MAX_BATCH", "1")),
+                         precision=os.environ.get("IVIT_PRECISION", "bf16"))
