@@ -375,3 +375,12 @@ def test_ln_fold_guard_on_a_high_mean_checkpoint():
         assert r2 <= 0.5 and eng.ln_fold, r2
     finally:
         eng.close()
+
+
+def test_config2_vit_b16_batch64_f16_as_dispatched():
+    """The same shapes on the f16 data path (IVIT_PRECISION_F16): f16 instantiations of the same tiles, every step gated on
+    identical operand bytes (one unit of f16 = 2^-11: eight times finer than the bf16 gate)."""
+    run_config("vit_b_16", 64, "f16",
+               {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs",
+                "mlp1": "ivit_gemm_f16_160x128x64_lf", "mlp2": "ivit_gemm_f16_160x128x64"},
+               expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)

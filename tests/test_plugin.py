@@ -119,3 +119,45 @@ def test_variant_table_matches_survey():
     assert round(VARIANTS["vit_l_16_384"].macs_per_image() / 1e9, 3) == 191.066
     assert round(VARIANTS["vit_h_14"].macs_per_image() / 1e9, 3) == 167.295
     assert VARIANTS["vit_l_16_384"].tokens == 577 and VARIANTS["vit_h_14"].tokens == 257
+
+
+def test_pending_tensor_waits_once_and_only_when_read():
+    """engine.PendingTensor (the lazily synchronised output of the asynchronous host path, include/ivit.h:
+    ivit_forward_host_async): the engine-side bookkeeping must not wait, any torch operation must wait exactly once and
+    return plain tensors - checked here against a stand-in engine that counts ivit_host_wait calls (no GPU needed)."""
+    import ctypes
+    from interactive_vit_amd.engine import PendingTensor
+
+    class Lib:
+        def __init__(self):
+            self.calls = []
+
+        def ivit_host_wait(self, h, ticket):
+            self.calls.append(int(ticket.value))
+            return 0
+
+    class Eng:
+        def __init__(self):
+            self.lib = Lib()
+            self._h = ctypes.c_void_p(1)
+
+        def _check(self, rc):
+            assert rc == 0
+
+    eng = Eng()
+    base = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    t = PendingTensor.wrap(base, eng, 7)
+    assert isinstance(t, torch.Tensor) and t._ivit_shape == (2, 3) and t._ivit_ptr == base.data_ptr()
+    with torch._C.DisableTorchFunctionSubclass():          # what Engine.forward does with a chained input
+        _ = t._version
+        view = t.detach().to(torch.float32).contiguous()
+        assert view.data_ptr() == base.data_ptr()
+    assert eng.lib.calls == []
+    assert t.numpy().shape == (2, 3)                        # Response.encode's access (reference main/message.py:114)
+    assert eng.lib.calls == [7]
+    u = t * 2 + t
+    assert type(u) is torch.Tensor and torch.equal(u, base * 3) and eng.lib.calls == [7]
+    assert torch.equal(t, base) and tuple(t.shape) == (2, 3) and eng.lib.calls == [7]
+    t2 = PendingTensor.wrap(base.clone(), eng, 9)
+    t2.mul_(0.5)                                            # an in-place write waits first, then bumps the version
+    assert eng.lib.calls == [7, 9]
