@@ -67,11 +67,17 @@ const int kRcclFloat32 = 7;                              // ncclFloat32 (rccl.h 
 int rccl_load(std::string* why) {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.lib) return 0;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    void* lib = nullptr;
-    for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!lib) { *why = std::string("librccl.so not found: ") + dlerror(); return 1; }
-    Rccl r; r.lib = lib;
+    // A process that already carries RCCL (torch.distributed's "nccl" backend loads its own copy) must not get a second one:
+    // bind to the loaded symbols first, dlopen only when there are none.
+    Rccl r;
+    void* lib = RTLD_DEFAULT;
+    if (!dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+        lib = nullptr;
+        for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!lib) { *why = std::string("librccl.so not found: ") + dlerror(); return 1; }
+    }
+    r.lib = lib ? lib : (void*)1;
     r.get_unique_id = (int (*)(RcclUniqueId*))dlsym(lib, "ncclGetUniqueId");
     r.comm_init_rank = (int (*)(RcclComm*, int, RcclUniqueId, int))dlsym(lib, "ncclCommInitRank");
     r.all_gather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))dlsym(lib, "ncclAllGather");
