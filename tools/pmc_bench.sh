@@ -22,7 +22,9 @@ out, tag, extra = sys.argv[1], sys.argv[2], sys.argv[3]
 def opt(name, default):
     m = re.search(name + r"[ =](\S+)", extra)
     return m.group(1) if m else default
-workload = f"--model {opt('--model', 'vit_b_16')} --batch-per-gpu {opt('--batch-per-gpu', '64')} --precision {opt('--precision', 'bf16')}"
+configs = {"2": ("vit_b_16", "64", "bf16"), "3": ("vit_l_16_384", "128", "bf16"), "4": ("vit_b_16", "256", "bf16"), "5": ("vit_h_14", "256", "fp8")}   # bench.py CONFIGS
+cm, cb, cp = configs[opt('--config', '2')]
+workload = f"--model {opt('--model', cm)} --batch-per-gpu {opt('--batch-per-gpu', cb)} --precision {opt('--precision', cp)}"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
