@@ -263,7 +263,8 @@ static hipError_t launch_nkf_op(const AttnParams& p, hipStream_t stream) {
     const int blocks = ceil_div(p.tokens, 16);
     // every wave gets at least one 16-query block.  (Measured at 197 keys, three 5-wave workgroups per CU -
     // which the 53-KiB ODD image allows - against two of 7-8 waves: 0.333 vs 0.307 ms per 12 launches; the
-    // launch moves 58 + 19 MB in 25 us and is bound by that, not by the 1.5-round grid.)
+    // launch moves 58 + 19 MB in 25 us and is bound by that, not by the 1.5-round grid.  Round 2, same question with up to 13
+    // waves - one 16-query block each, one workgroup per CU: 5 / 7 / 8 / 10 / 13 waves -> 0.372 / 0.315 / 0.312 / 0.344 / 0.354 ms.)
     // IVIT_ATT_WAVES (experiment knob): waves per workgroup at <= 224 keys (default 8)
     static const int max_waves = [] { const char* v = getenv("IVIT_ATT_WAVES"); const int w = v ? atoi(v) : 8; return (w >= 1 && w <= 16) ? w : 8; }();
     const int waves = std::min(NKF <= 14 ? max_waves : 8, blocks);
