@@ -21,7 +21,6 @@
 // half (keys 32 s + 4 g .. +3, then +16).  V's 16-B chunks are XOR-swizzled by ((key >> 1) & 3) << 1,
 // which makes those reads bank-conflict free.  Softmax statistics are fp32; row max / sum are wavefront shuffles across the 4 lane groups.
 #include "kernels.h"
-#include <cstdlib>
 #include <algorithm>
 
 namespace ivit {
@@ -84,7 +83,7 @@ __device__ __forceinline__ void att_stage(char* lds, const bf16_t* src0, int ld,
 
 // OP: the 16-bit type of q|k|v, of the softmax numerators fed to P.V and of the output (OpBf16 / OpF16, common.h)
 template <int DH, int NKF, bool ODD, bool PROBS, class OP>
-__global__ __launch_bounds__(NKF <= 14 ? 1024 : 512) void ivit_attention_bf16(AttnParams p) {
+__global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     using L = AttLayout<DH, NKF, ODD>;
     constexpr int ATT_DH = DH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -265,9 +264,7 @@ static hipError_t launch_nkf_op(const AttnParams& p, hipStream_t stream) {
     // which the 53-KiB ODD image allows - against two of 7-8 waves: 0.333 vs 0.307 ms per 12 launches; the
     // launch moves 58 + 19 MB in 25 us and is bound by that, not by the 1.5-round grid.  Round 2, same question with up to 13
     // waves - one 16-query block each, one workgroup per CU: 5 / 7 / 8 / 10 / 13 waves -> 0.372 / 0.315 / 0.312 / 0.344 / 0.354 ms.)
-    // IVIT_ATT_WAVES (experiment knob): waves per workgroup at <= 224 keys (default 8)
-    static const int max_waves = [] { const char* v = getenv("IVIT_ATT_WAVES"); const int w = v ? atoi(v) : 8; return (w >= 1 && w <= 16) ? w : 8; }();
-    const int waves = std::min(NKF <= 14 ? max_waves : 8, blocks);
+    const int waves = std::min(8, blocks);
     dim3 grid(1, p.heads, p.batch);
     hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, ODD, PROBS, OP>), grid, dim3(waves * 64), L::LDS_BYTES, stream, p);
     return hipGetLastError();
