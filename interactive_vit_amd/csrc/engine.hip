@@ -916,7 +916,10 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
     if (in_token != 0 && in_token == e->resident_token && n_in == e->resident_elems) {
         std::swap(e->ext_in, e->ext_out);   // the previous call's output is this call's input: no upload
     } else {
-        if (ext_buffer_writable(e, e->ext_in, st)) return 1;
+        // `in` may be the page-locked output of an earlier asynchronous call of this engine whose D2H copy (copy stream)
+        // is still in flight: the upload must come after EVERY pending copy, not only the one that read its target buffer
+        if (ext_buffer_writable(e, e->ext_buf0, st)) return 1;
+        if (ext_buffer_writable(e, e->ext_in == e->ext_buf0 ? e->ext_out : e->ext_in, st)) return 1;
         HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
     }
     if (ext_buffer_writable(e, e->ext_out, st)) return 1;   // the copy of two calls ago may still be reading it

@@ -268,6 +268,8 @@ class Engine:
             # node chains: when `x` is the very tensor the previous host call returned (Context.compute
             # hands outputs on by reference) and nobody wrote to it since, its device-resident copy is
             # consumed instead of uploading it again (include/ivit.h: ivit_forward_host_chained)
+            if isinstance(x, PendingTensor) and x._ivit_engine() is not self:
+                x._ivit_wait()            # another engine's copy stream fills it: nothing of ours is ordered behind that
             with torch._C.DisableTorchFunctionSubclass():      # no torch call below may wait for a pending copy
                 token = 0
                 last = self._last_out

@@ -718,5 +718,15 @@ def test_async_host_outputs_are_lazy_and_bit_identical(small, monkeypatch):
         d = eng.forward(img, 0, 1)
         d.mul_(0.5)
         assert torch.equal(eng.forward(d, 1, 2), sync_eng.forward(want[0] * 0.5, 1, 2))
+        # a pending tensor of ONE engine as the input of ANOTHER (two model plugins chained in a graph): nothing of the second
+        # engine is ordered behind the first one's copy stream, so the binding waits before the upload
+        monkeypatch.setenv("IVIT_ASYNC_OUTPUTS", "1")
+        other = Engine(cfg, sd, device=0, max_batch=5)
+        try:
+            for _ in range(3):
+                a = eng.forward(img, 0, 2)               # pending, owned by `eng`
+                assert torch.equal(other.forward(a, 2, 3), want[2])
+        finally:
+            other.close()
     finally:
         sync_eng.close()
