@@ -589,4 +589,77 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
 #endif
 }
 
+// ---- small-M tile with a deep DMA ring (the interactive path: one to a few images, M = 197 ... ~1000 token rows).
+// At these sizes a grid is a handful of workgroups and every K-tile of the two-stage gemm_body pays a full L2 -> LDS round
+// trip (0.9 us: the MLP-down GEMM of ONE image, K = 3072, took 45 us on 12 workgroups).  Here STAGES - 1 K-tiles of DMA are in
+// flight behind a counted s_waitcnt (every wave issues the same number of pieces per K-tile, surplus stagings past the end
+// re-load the last K-tile into a dead slot so the count is a constant), one raw barrier per K-tile.  Same MFMA, same K
+// order, same epilogues: bit-identical to the other tiles (the batch-independence tests compare across them).
+template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int STAGES_>
+struct GemmTileDeep : GemmTile<WAVES_M_, WAVES_N_, FM_, FN_> {
+    using Base = GemmTile<WAVES_M_, WAVES_N_, FM_, FN_>;
+    static constexpr int STAGES = STAGES_;
+    static constexpr int LDS_BYTES = STAGES * Base::STAGE_BYTES;
+    static constexpr int PIECES_PER_WAVE = (Base::A_PIECES + Base::W_PIECES) / Base::WAVES;
+    static_assert(Base::A_PIECES % Base::WAVES == 0 && Base::W_PIECES % Base::WAVES == 0, "every wave must issue the same number of DMA pieces");
+};
+
+template <class T, int EK = 0, class OP = OpBf16>
+__device__ __forceinline__ void gemm_body_deep(const GemmParams& p, char* smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / T::WAVES_N, wc = wave % T::WAVES_N;
+    int tm, tn;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
+    const int m0 = tm * T::BM, n0 = tn * T::BN;
+
+    f32x4 acc[T::FM][T::FN];
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
+    const int nt = p.K / GEMM_BK, last = nt - 1;
+    float2* tile_stats = reinterpret_cast<float2*>(smem + T::LDS_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
+    if (EK == 2) {
+        ln_tile_stats<T>(p, m0, tile_stats);   // ordinary loads: before any DMA is in flight
+        __syncthreads();
+    }
+    auto stage = [&](int kt, int slot) {
+        char* dst = smem + slot * T::STAGE_BYTES;
+        stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, min(kt, last) * 128, dst, wave, lane);
+        stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, min(kt, last) * 128, dst + T::A_BYTES, wave, lane);
+    };
+#pragma unroll
+    for (int s = 0; s < T::STAGES - 1; ++s) stage(s, s);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int slot = 0;
+    for (int t = 0; t < nt; ++t) {
+        // K-tile t has landed for this wave (all but the STAGES - 2 newest stagings); the barrier publishes everyone's pieces and
+        // separates the reads of K-tile t - 1 from the staging that now overwrites its slot
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((T::STAGES - 2) * T::PIECES_PER_WAVE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(t + T::STAGES - 1, slot == 0 ? T::STAGES - 1 : slot - 1);
+        const char* a_tile = smem + slot * T::STAGE_BYTES;
+        const char* w_tile = a_tile + T::A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[T::FM], wf[T::FN];
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) wf[j] = read_frag(w_tile, (wc * T::FN + j) * 16 + fr, kk * 4 + fq);
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i) af[i] = read_frag(a_tile, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) acc[i][j] = OP::mfma(wf[j], af[i], acc[i][j]);
+        }
+        slot = slot + 1 == T::STAGES ? 0 : slot + 1;
+    }
+    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus stagings past the end still write LDS
+}
+
 }  // namespace ivit

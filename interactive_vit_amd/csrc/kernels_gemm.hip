@@ -61,6 +61,23 @@ __global__ __launch_bounds__(TilePE::THREADS, 2) void ivit_gemm_bf16_256x128x64_
     gemmpe_body<OpBf16, true>(p, smem);
 }
 
+// small-M tile with a deep DMA ring (gemm_kernel.h: gemm_body_deep): 64 x 128, 8 waves of 16 x 64 (two per SIMD: one wave's DMA issue
+// and LDS reads run beside its partner's MFMAs), four stages = 96 KiB LDS, one workgroup per CU.  Measured at M = 197 (one image):
+// four waves of 32 x 64 took 0.5 us per K-tile with four stages AND with six - issue-bound, not latency-bound.
+using Tile64D = GemmTileDeep<4, 2, 1, 4, 4>;
+#define IVIT_DEEP_KERNEL(NAME, EK, OP)                                                       \
+    __global__ __launch_bounds__(Tile64D::THREADS, 1) void NAME(GemmParams p) {              \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
+        gemm_body_deep<Tile64D, EK, OP>(p, smem);                                             \
+    }
+IVIT_DEEP_KERNEL(ivit_gemm_bf16_64x128x64_deep, 0, OpBf16)
+IVIT_DEEP_KERNEL(ivit_gemm_bf16_64x128x64_deep_rs, 1, OpBf16)
+IVIT_DEEP_KERNEL(ivit_gemm_bf16_64x128x64_deep_lf, 2, OpBf16)
+IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep, 0, OpF16)
+IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_rs, 1, OpF16)
+IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_lf, 2, OpF16)
+#undef IVIT_DEEP_KERNEL
+
 // f16 operands (IVIT_PRECISION_F16): the same bodies on v_mfma_f32_16x16x32_f16 with f16 outputs (same rate as bf16, 11 bits)
 #define IVIT_F16_KERNEL(NAME, THREADS_, BODY)                                                  \
     __global__ __launch_bounds__(THREADS_, 2) void NAME(GemmParams p) {                        \
@@ -145,6 +162,7 @@ const char* gemm_variant_name(int v) {
         case GEMM_TILE_160X256W4: return "ivit_gemm_bf16_160x256x64_w4";
         case GEMM_TILE_256PS: return "ivit_gemm_bf16_256x256x64_persist";
         case GEMM_TILE_PE: return "ivit_gemm_bf16_256x128x64_pe";
+        case GEMM_TILE_64D: return "ivit_gemm_bf16_64x128x64_deep";
     }
     return "?";
 }
@@ -199,7 +217,11 @@ bool gemm_prefers_256(int M, int N, int K) {
     return rounds >= 3.0;
 }
 
+// Small grids (the interactive path: one to a few 197-token images; the classifier head of any batch): when the 64 x 128 tiles of a
+// shape fit one round of one workgroup per CU, every K-tile of the two-stage tiles is a DMA round trip - the deep-ring tile takes
+// those (tools/gemm_bench at M = 197: qkv 10.8 -> 7.3 us, proj 13.2 -> 8.1, mlp1 12.1 -> 7.9, mlp2 33.9 -> 19.3; bit-identical).
 int gemm_pick_variant(int M, int N, int K) {
+    if (K >= 2 * GEMM_BK && ceil_div(M, Tile64D::BM) * ceil_div(N, Tile64D::BN) <= 256) return GEMM_TILE_64D;
     if (gemm_prefers_256(M, N, K)) return GEMM_TILE_256S;
     struct Cand { int v, bm, bn; double speed; };
     static const Cand cands[] = {
@@ -284,6 +306,7 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
             case GEMM_TILE_128: return launch_tile<Tile128>(family == 0 ? ivit_gemm_f16_128x128x64 : family == 1 ? ivit_gemm_f16_128x128x64_rs : ivit_gemm_f16_128x128x64_lf, p, stream, Tile128::BM * extra);
             case GEMM_TILE_160: return launch_tile<Tile160>(family == 0 ? ivit_gemm_f16_160x128x64 : family == 1 ? ivit_gemm_f16_160x128x64_rs : ivit_gemm_f16_160x128x64_lf, p, stream, Tile160::BM * extra);
             case GEMM_TILE_256S: return launch_tile<Tile256P>(family == 0 ? ivit_gemm_f16_256x256x64_stag : family == 1 ? ivit_gemm_f16_256x256x64_stag_rs : ivit_gemm_f16_256x256x64_stag_lf, p, stream, Tile256P::BM * extra);
+            case GEMM_TILE_64D: return launch_tile<Tile64D>(family == 0 ? ivit_gemm_f16_64x128x64_deep : family == 1 ? ivit_gemm_f16_64x128x64_deep_rs : ivit_gemm_f16_64x128x64_deep_lf, p, stream, Tile64D::BM * extra);
             default: return hipErrorInvalidValue;
         }
     }
@@ -292,10 +315,12 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
             case GEMM_TILE_128: return family == 1 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_rs, p, stream) : launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_lf, p, stream, Tile128::BM * 8);
             case GEMM_TILE_160: return family == 1 ? launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_rs, p, stream) : launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_lf, p, stream, Tile160::BM * 8);
             case GEMM_TILE_256S: return family == 1 ? launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_rs, p, stream) : launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_lf, p, stream, Tile256P::BM * 8);
+            case GEMM_TILE_64D: return family == 1 ? launch_tile<Tile64D>(ivit_gemm_bf16_64x128x64_deep_rs, p, stream) : launch_tile<Tile64D>(ivit_gemm_bf16_64x128x64_deep_lf, p, stream, Tile64D::BM * 8);
             default: return hipErrorInvalidValue;
         }
     }
     switch (variant) {
+        case GEMM_TILE_64D: return launch_tile<Tile64D>(ivit_gemm_bf16_64x128x64_deep, p, stream);
         case GEMM_TILE_128: return launch_tile<Tile128>(ivit_gemm_bf16_128x128x64, p, stream);
         case GEMM_TILE_160: return launch_tile<Tile160>(ivit_gemm_bf16_160x128x64, p, stream);
 #ifdef IVIT_GEMM_ABLATIONS
@@ -338,6 +363,11 @@ const char* gemm_fp8_kernel_name(const GemmParams& p) {
 const char* gemm_kernel_name(const GemmParams& p) {
     const int v = gemm_pick_variant(p.M, p.N, p.K);
     const int family = p.epi == EPI_BIAS_RESID_STATS ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
+    if (v == GEMM_TILE_64D) {
+        static const char* deep[2][3] = {{"ivit_gemm_bf16_64x128x64_deep", "ivit_gemm_bf16_64x128x64_deep_rs", "ivit_gemm_bf16_64x128x64_deep_lf"},
+                                         {"ivit_gemm_f16_64x128x64_deep", "ivit_gemm_f16_64x128x64_deep_rs", "ivit_gemm_f16_64x128x64_deep_lf"}};
+        return deep[p.f16 ? 1 : 0][family];
+    }
     static const char* names[3][3] = {
         {"ivit_gemm_bf16_128x128x64", "ivit_gemm_bf16_128x128x64_rs", "ivit_gemm_bf16_128x128x64_lf"},
         {"ivit_gemm_bf16_160x128x64", "ivit_gemm_bf16_160x128x64_rs", "ivit_gemm_bf16_160x128x64_lf"},

@@ -50,7 +50,9 @@ int main(int argc, char** argv) {
                   {"l_mlp1", Mfull, 4096, 1024, EPI_BIAS_GELU_BF16}, {"l_mlp2", Mfull, 1024, 4096, EPI_BIAS_RESID_F32}};
     int maxN = 0, maxK = 0;
     for (const Shape& s : shapes) { maxN = std::max(maxN, s.N); maxK = std::max(maxK, s.K); }
-    const int maxM = round_up(Mfull, 256) + 256;
+    int maxMs = Mfull;
+    for (const Shape& s : shapes) maxMs = std::max(maxMs, s.M);   // (the patch shape has its own M)
+    const int maxM = round_up(maxMs, 256) + 256;
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> u(-1.f, 1.f);
     std::vector<bf16_t> hA((size_t)maxM * maxK), hW((size_t)maxN * maxK);
@@ -166,7 +168,7 @@ int main(int argc, char** argv) {
         if (s.epi == EPI_BIAS_RESID_STATS) {   // the statistics and the bf16 copy must not depend on the tile shape: bitwise
             std::vector<unsigned long long> base, cur((size_t)s.M * GEMM_LN_SLOTS);
             std::vector<unsigned short> xbase, xcur((size_t)s.M * s.N);
-            for (int v : {GEMM_TILE_160, GEMM_TILE_128, GEMM_TILE_256S}) {
+            for (int v : {GEMM_TILE_160, GEMM_TILE_128, GEMM_TILE_256S, GEMM_TILE_64D}) {
                 CK(hipMemset(dpart, 0, (size_t)s.M * GEMM_LN_SLOTS * 8));
                 CK(launch_gemm_variant(p, v, 0));
                 CK(hipDeviceSynchronize());
@@ -184,12 +186,26 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        if ((vmask >> GEMM_TILE_64D) & 1) {   // the deep-ring small-M tile: the shape's own epilogue BITWISE against the 160x128 kernel
+            const bool out16 = s.epi == EPI_BIAS_BF16 || s.epi == EPI_BIAS_GELU_BF16 || s.epi == EPI_LNFOLD_BF16 || s.epi == EPI_LNFOLD_GELU_BF16;
+            const size_t bytes = (size_t)s.M * s.N * (out16 ? 2 : 4);
+            std::vector<unsigned char> ref(bytes), got(bytes);
+            GemmParams a = p; a.debug = 0;
+            if (a.epi == EPI_BIAS_RESID_F32 || a.epi == EPI_BIAS_RESID_STATS) { a.out = dout; a.resid = dres; }   // out of place: both runs read the same residual
+            CK(launch_gemm_variant(a, GEMM_TILE_160, 0)); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(ref.data(), dout, bytes, hipMemcpyDeviceToHost));
+            CK(hipMemset(dout, 0xff, bytes));
+            CK(launch_gemm_variant(a, GEMM_TILE_64D, 0)); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(got.data(), dout, bytes, hipMemcpyDeviceToHost));
+            size_t bad = 0; for (size_t i = 0; i < bytes; ++i) bad += got[i] != ref[i];
+            printf("   %-28s own epilogue vs 160x128: %zu of %zu output bytes differ%s\n", gemm_variant_name(GEMM_TILE_64D), bad, bytes, bad ? "" : " (bit-identical)");
+        }
         std::vector<std::vector<double>> ctimes(cfgs.size() * GEMM_VARIANTS);
         for (int round = 0; round < rounds; ++round)
             for (size_t ci = 0; ci < cfgs.size(); ++ci)
             for (int v = 0; v < GEMM_VARIANTS; ++v) {
                 if (!((vmask >> v) & 1)) continue;
-                if (s.epi >= EPI_BIAS_RESID_STATS && v != GEMM_TILE_128 && v != GEMM_TILE_160 && v != GEMM_TILE_256S && v != GEMM_TILE_PE) continue;
+                if (s.epi >= EPI_BIAS_RESID_STATS && v != GEMM_TILE_128 && v != GEMM_TILE_160 && v != GEMM_TILE_256S && v != GEMM_TILE_PE && v != GEMM_TILE_64D) continue;
                 if (v == GEMM_TILE_PE && !gemm_pe_supported(p)) continue;
                 if (ci > 0 && v != GEMM_TILE_128 && v != GEMM_TILE_160) continue;   // the ablation knobs live in gemm_body
                 if (cfgs[ci].order == 2 && (v != GEMM_TILE_160 || ceil_div(s.M, 160) * ceil_div(s.N, 128) > 512 || (ceil_div(s.N, 128) & 1))) continue;
