@@ -48,7 +48,7 @@ struct GemmParams {
     int order;                      // microbenchmark builds only: 1 = row bands per XCD (tile_coords_banded), 2 = pairs sharing a CU (gemm_body)
 };
 
-enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_TILE_PE = 8, GEMM_TILE_64D = 9, GEMM_TILE_128D = 10, GEMM_TILE_160D = 11, GEMM_VARIANTS = 12 };
+enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_TILE_PE = 8, GEMM_TILE_64D = 9, GEMM_VARIANTS = 10 };
 // GEMM_TILE_PE (gemmpe_kernel.h: persistent 256 x 128, epilogue interleaved into the next tile's main loop) serves the 16-bit-output
 // epilogues only; gemm_pe_supported says whether a call can take it (shape limits, LayerNorm operands as per-slot pairs)
 bool gemm_pe_supported(const GemmParams& p);

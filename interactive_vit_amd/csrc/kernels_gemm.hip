@@ -113,17 +113,8 @@ __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_fp8_256x256x12
     gemm256s_body<0, true>(p, smem);
 }
 #ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost, and timing ablations
-// is the 128-class main loop bound by L2 -> LDS bandwidth or by bytes in flight?  The same tiles on the deep ring, one workgroup per CU:
-using Tile128D = GemmTileDeep<2, 2, 4, 4, 4>;   // 128 x 128, 4 waves, 4 stages = 128 KiB: 96 KiB in flight (2 x 2-stage workgroups: 64)
-using Tile160D = GemmTileDeep<2, 2, 5, 4, 4>;   // 160 x 128, 4 waves, 4 stages = 144 KiB: 108 KiB in flight (2 x 2-stage workgroups: 72)
-__global__ __launch_bounds__(Tile128D::THREADS, 1) void ivit_gemm_bf16_128x128x64_deep(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body_deep<Tile128D, 0, OpBf16>(p, smem);
-}
-__global__ __launch_bounds__(Tile160D::THREADS, 1) void ivit_gemm_bf16_160x128x64_deep(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body_deep<Tile160D, 0, OpBf16>(p, smem);
-}
+// (the 128 x 128 / 160 x 128 tiles on the deep ring of gemm_body_deep, one 4-wave workgroup per CU, were measured too: 87-138 us where the
+// two-stage two-per-CU kernels take 53-77 us - one wave per SIMD cannot cover its own DMA issue)
 __global__ __launch_bounds__(Tile160x256W4::THREADS, 1) void ivit_gemm_bf16_160x256x64_w4(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm160x256w4_body(p, smem);
@@ -174,8 +165,6 @@ const char* gemm_variant_name(int v) {
         case GEMM_TILE_256PS: return "ivit_gemm_bf16_256x256x64_persist";
         case GEMM_TILE_PE: return "ivit_gemm_bf16_256x128x64_pe";
         case GEMM_TILE_64D: return "ivit_gemm_bf16_64x128x64_deep";
-        case GEMM_TILE_128D: return "ivit_gemm_bf16_128x128x64_deep";
-        case GEMM_TILE_160D: return "ivit_gemm_bf16_160x128x64_deep";
     }
     return "?";
 }
@@ -337,8 +326,6 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
         case GEMM_TILE_128: return launch_tile<Tile128>(ivit_gemm_bf16_128x128x64, p, stream);
         case GEMM_TILE_160: return launch_tile<Tile160>(ivit_gemm_bf16_160x128x64, p, stream);
 #ifdef IVIT_GEMM_ABLATIONS
-        case GEMM_TILE_128D: return launch_tile<Tile128D>(ivit_gemm_bf16_128x128x64_deep, p, stream);
-        case GEMM_TILE_160D: return launch_tile<Tile160D>(ivit_gemm_bf16_160x128x64_deep, p, stream);
         case GEMM_TILE_256: return launch_tile<Tile256>(ivit_gemm_bf16_256x256x64, p, stream);
         case GEMM_TILE_256P:
             if (p.debug == 1) return launch_tile<Tile256P>(ivit_gemm_256pipe_nodma, p, stream);
