@@ -349,6 +349,22 @@ __device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 
 // (the loads overlap the first operand DMA).  Source: finished statistics (ln_stats: ivit_row_stats wrote them) or the
 // per-64-column (sum, M2) pairs a residual GEMM left (ln_part), folded in slot order with Chan's formula - exact
 // two-pass statistics, the same bits whatever tile shape wrote the pairs and whichever column tile folds them.
+// Chan's update of a row's running (mean, M2) with the (sum, M2) pair of 64-column slot s2 (callers unroll fully, so s2 and the
+// ratios below are compile-time constants).  Shared by every consumer of the per-slot pairs: they all fold identically.
+__device__ __forceinline__ void ln_chan_update(float& mean, float& m2, float sm, float mm, int s2, int ln_dim) {
+    constexpr float inv64 = 1.0f / 64.0f;
+    const int nk = min(64, ln_dim - s2 * 64);
+    if (nk == 64) {
+        const float d = fmaf(sm, inv64, -mean);
+        mean = fmaf(d, 1.0f / (float)(s2 + 1), mean);
+        m2 = fmaf(d * d, 64.0f * (float)s2 / (float)(s2 + 1), m2 + mm);
+    } else {                                   // the last, ragged slot of a width that is not a multiple of 64
+        const float nb = (float)nk, na = 64.0f * (float)s2, nn = na + nb, d = sm / nb - mean;
+        mean = fmaf(d, nb / nn, mean);
+        m2 = fmaf(d * d, na * nb / nn, m2 + mm);
+    }
+}
+
 template <class T>
 __device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float2* tile_stats, const float4* first = nullptr) {
     for (int r = threadIdx.x; r < T::BM; r += T::THREADS) {
@@ -372,20 +388,10 @@ __device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float
                 for (int l = 0; l < 6; ++l) raw[l] = (s0 == 0 && first) ? first[l] : pr[min((s0 >> 1) + l, GEMM_LN_SLOTS / 2 - 1)];   // the first 12 slots may have been loaded ahead (ln_tile_stats_prefetch)
 #pragma unroll
                 for (int q = 0; q < 12; ++q) {
-                    constexpr float inv64 = 1.0f / 64.0f;
                     const int s2 = s0 + q;                     // compile-time after unrolling
                     if (s2 >= GEMM_LN_SLOTS || s2 >= nslots) continue;
                     const float sm = (q & 1) ? raw[q >> 1].z : raw[q >> 1].x, mm = (q & 1) ? raw[q >> 1].w : raw[q >> 1].y;
-                    const int nk = min(64, p.ln_dim - s2 * 64);
-                    if (nk == 64) {
-                        const float d = fmaf(sm, inv64, -mean);
-                        mean = fmaf(d, 1.0f / (float)(s2 + 1), mean);
-                        m2 = fmaf(d * d, 64.0f * (float)s2 / (float)(s2 + 1), m2 + mm);
-                    } else {                                   // the last, ragged slot of a width that is not a multiple of 64
-                        const float nb = (float)nk, na = 64.0f * (float)s2, nn = na + nb, d = sm / nb - mean;
-                        mean = fmaf(d, nb / nn, mean);
-                        m2 = fmaf(d * d, na * nb / nn, m2 + mm);
-                    }
+                    ln_chan_update(mean, m2, sm, mm, s2, p.ln_dim);
                 }
             }
             st = make_float2(mean, 1.0f / sqrtf(m2 / (float)p.ln_dim + p.ln_eps));

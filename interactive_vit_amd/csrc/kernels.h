@@ -79,6 +79,24 @@ struct AttnParams {
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 bool attention_supported(int tokens, int head_dim);
 
+// Fused QKV projection (LayerNorm folded) + attention, one workgroup per (image, head), for <= 224 tokens at head dim 64: the
+// q|k|v tensor stays in LDS (kernels_attn.hip: ivit_qkv_attention_fused).  Same values as launch_gemm(EPI_LNFOLD_BF16) followed by
+// launch_attention, bit for bit.
+struct FusedQkvAttnArgs {
+    const bf16_t* x; int ldx;            // [rows_total, D] 16-bit operand copy of the residual stream
+    const bf16_t* w; int ldw;            // [3D, D] LayerNorm-folded in_proj weight
+    const float* c; const float* s;      // [3D] fold vectors (bias + W beta; row sums of W')
+    const float2* ln_part; const float2* ln_stats; float ln_eps;   // row statistics: per-slot pairs, or finished (mean, rstd)
+    bf16_t* out; int ldo;                // [rows_total, D] attention output
+    bf16_t* qkv_dbg; int ldq;            // nullptr, or [rows_total, 3D]: also store q|k|v (inspection taps)
+    int batch, tokens, heads, head_dim, dim, rows_total, f16;
+    float scale;
+    unsigned long long* stamps;          // microbenchmark builds only: 8 s_memrealtime stamps per workgroup (nullptr in the product)
+    int debug;                           // microbenchmark builds only: ablations (0 in the product)
+};
+bool fused_qkv_attention_supported(int tokens, int head_dim, int dim);
+hipError_t launch_fused_qkv_attention(const FusedQkvAttnArgs& a, hipStream_t stream);
+
 // ---------------------------------------------------------------- misc (kernels_misc.hip)
 // (x - mean[c]) / std[c] on [B,3,S,S] f32
 hipError_t launch_transform(const float* in, float* out, int batch, int image, hipStream_t s);
