@@ -634,22 +634,24 @@ static int run_fused_qkv_attention(ivit_engine* e, const Ws& w, hipStream_t st, 
 enum { TAP_NONE = 0, TAP_H1 = 1, TAP_QKV = 2, TAP_ATT = 3, TAP_PROJ = 4, TAP_H2 = 5, TAP_U = 6, TAP_OUT = 7 };
 
 // fp8 data path of one encoder layer (IVIT_PRECISION_FP8, after calibration)
-static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B, int tap = TAP_NONE) {
+static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B, int tap = TAP_NONE, const float* xi = nullptr, float* xo = nullptr) {
     const int D = e->D, M = B * e->N;
     LayerWeights& lw = e->layers[li];
-    if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, nullptr, nullptr, w.h8, 1.0f / lw.s_h1)) return 1;
+    if (!xi) xi = w.x;
+    if (!xo) xo = w.x;
+    if (run_layernorm(e, st, xi, 1, M, lw.ln1_g, lw.ln1_b, nullptr, nullptr, w.h8, 1.0f / lw.s_h1)) return 1;
     if (tap == TAP_H1) return 0;
     if (run_gemm_fp8(e, st, w.h8, e->ld8d, lw.q_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, 1.0f, "qkv")) return 1;
     if (tap == TAP_QKV) return 0;
     if (run_attention(e, w, st, B, w.att8, 1.0f / lw.s_att)) return 1;
     if (tap == TAP_ATT) return 0;
-    if (run_gemm_fp8(e, st, w.att8, e->ld8d, lw.q_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D, 1.0f, "proj")) return 1;
+    if (run_gemm_fp8(e, st, w.att8, e->ld8d, lw.q_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, xi, D, 1.0f, "proj")) return 1;
     if (tap == TAP_PROJ) return 0;
     if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, nullptr, nullptr, w.h8, 1.0f / lw.s_h2)) return 1;
     if (tap == TAP_H2) return 0;
     if (run_gemm_fp8(e, st, w.h8, e->ld8d, lw.q1, M, lw.b1, EPI_BIAS_GELU_FP8, w.u8, e->ld8m, nullptr, 0, 1.0f / lw.s_u, "mlp1")) return 1;
     if (tap == TAP_U) return 0;
-    if (run_gemm_fp8(e, st, w.u8, e->ld8m, lw.q2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D, 1.0f, "mlp2")) return 1;
+    if (run_gemm_fp8(e, st, w.u8, e->ld8m, lw.q2, M, lw.b2, EPI_BIAS_RESID_F32, xo, D, w.x, D, 1.0f, "mlp2")) return 1;
     return 0;
 }
 
@@ -669,32 +671,37 @@ static bool fold_for_rows(const ivit_engine* e, int M) {
 // residual GEMM that produced x (EPI_BIAS_RESID_STATS), or by ivit_row_stats where no GEMM did.
 // `stats_in`: x's statistics / bf16 copy already exist (the previous layer's MLP-down GEMM wrote them);
 // `stats_out`: a layer follows in this call, so this layer's MLP-down GEMM writes them for it.
+// `xi` / `xo`: where the layer reads its input stream and leaves its output (default: in place in w.x).  A node that runs one
+// layer on a chained input hands the caller's buffers in - the out-projection takes its residual from xi, the MLP-down GEMM
+// writes xo - instead of copying the stream into and out of w.x (two 0.6 MB copies = 16 us per single-image node).
 static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B, float* amax4 = nullptr, bool stats_in = false,
-                     bool stats_out = false, int tap = TAP_NONE) {
+                     bool stats_out = false, int tap = TAP_NONE, const float* xi = nullptr, float* xo = nullptr) {
     const int D = e->D, M = B * e->N, Mlp = e->cfg.mlp;
     LayerWeights& lw = e->layers[li];
+    if (!xi) xi = w.x;
+    if (!xo) xo = w.x;
     if (e->ratio_on) {
         // LayerNorm-fold calibration: the unfolded path below, with the |mean| / std of both LayerNorm inputs recorded
-        HIP_TRY(launch_row_mean_ratio(w.x, D, M, D, e->cfg.ln_eps, e->ratio_dev, st));
-        if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
+        HIP_TRY(launch_row_mean_ratio(xi, D, M, D, e->cfg.ln_eps, e->ratio_dev, st));
+        if (run_layernorm(e, st, xi, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
         if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "qkv")) return 1;
         if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
-        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
+        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, xi, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
         HIP_TRY(launch_row_mean_ratio(w.x, D, M, D, e->cfg.ln_eps, e->ratio_dev, st));
         if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, w.h, nullptr)) return 1;
         if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "mlp1")) return 1;
-        return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2");
+        return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, xo, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2");
     }
     if (!amax4 && e->cfg.precision == IVIT_PRECISION_FP8) {
         if (!e->fp8_ready) return fail("fp8 engine is not calibrated: call ivit_fp8_calibrate first");
-        return run_layer_fp8(e, w, st, li, B, tap);
+        return run_layer_fp8(e, w, st, li, B, tap, xi, xo);
     }
     if (!amax4 && fold_for_rows(e, M)) {
         LnFold fold; fold.part = w.ln_part; fold.xb = w.h;
         fold.stats = stats_in ? nullptr : w.ln_stats;      // finished statistics only where ivit_row_stats made them
         if (!stats_in) {
             ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * D * 6.0);
-            HIP_TRY(launch_row_stats(w.x, D, M, D, w.h, D, w.ln_stats, e->cfg.ln_eps, st, e->f16));
+            HIP_TRY(launch_row_stats(xi, D, M, D, w.h, D, w.ln_stats, e->cfg.ln_eps, st, e->f16));
         }
         if (tap == TAP_H1) return 0;
         fold.s = lw.s_in;
@@ -709,16 +716,16 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
             if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
             if (tap == TAP_ATT) return 0;
         }
-        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
+        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, xi, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
         if (tap == TAP_PROJ || tap == TAP_H2) return 0;
         fold.s = lw.s_1;
         fold.stats = nullptr;                               // the out-projection's epilogue left the pairs: fold them in the consumer
         if (run_gemm(e, st, w.h, D, lw.wf_1, M, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "mlp1")) return 1;
         if (tap == TAP_U) return 0;
-        if (stats_out) return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_STATS, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, &fold, "mlp2");
-        return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2");
+        if (stats_out) return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_STATS, xo, D, w.x, D, nullptr, 0, 0, 0, 0, &fold, "mlp2");
+        return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, xo, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2");
     }
-    if (run_layernorm(e, st, w.x, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
+    if (run_layernorm(e, st, xi, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.h, D, M, D, amax4 + 0, st));
     if (tap == TAP_H1) return 0;
     if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "qkv")) return 1;
@@ -726,7 +733,7 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
     if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.att, D, M, D, amax4 + 1, st));
     if (tap == TAP_ATT) return 0;
-    if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
+    if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, xi, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
     if (tap == TAP_PROJ) return 0;
     if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, w.h, nullptr)) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.h, D, M, D, amax4 + 2, st));
@@ -734,7 +741,7 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
     if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "mlp1")) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.u, Mlp, M, Mlp, amax4 + 3, st));
     if (tap == TAP_U) return 0;
-    if (run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, w.x, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2")) return 1;
+    if (run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, xo, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2")) return 1;
     return 0;
 }
 
@@ -799,18 +806,16 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
     }
     bool stats_ready = false;   // LayerNorm fold: the previous layer left x's statistics and bf16 copy behind
     for (; s < end && s < ST_LN; ++s) {
-        if (!in_x) {
-            HIP_TRY(hipMemcpyAsync(w.x, cur, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
-            in_x = true;
-        }
+        // the first layer of a range that starts on the caller's tensor reads it in place; the last layer of a range that ends on an
+        // encoder layer writes the caller's output (no copies of the stream into / out of w.x)
+        const float* xi = in_x ? nullptr : cur;
+        in_x = true;
         const bool more = (s + 1 < end) && (s + 1 < ST_LN);
-        if (run_layer(e, w, st, s - ST_LAYER0, B, nullptr, stats_ready, more)) return 1;
+        float* xo = (s + 1 == end) ? out : nullptr;
+        if (run_layer(e, w, st, s - ST_LAYER0, B, nullptr, stats_ready, more, TAP_NONE, xi, xo)) return 1;
         stats_ready = more && fold_for_rows(e, B * N);
     }
-    if (s >= end) {   // the range ended on an encoder layer: hand the residual stream out
-        HIP_TRY(hipMemcpyAsync(out, w.x, (size_t)B * N * D * 4, hipMemcpyDeviceToDevice, st));
-        return 0;
-    }
+    if (s >= end) return 0;   // the range ended on an encoder layer: its MLP-down GEMM wrote `out`
     if (s == ST_LN) {
         const float* src = in_x ? w.x : cur;
         if (end == ST_LN + 1) return run_layernorm(e, st, src, 1, B * N, e->lnf_g, e->lnf_b, nullptr, out);

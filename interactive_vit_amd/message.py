@@ -18,6 +18,7 @@ SURVEY 3.1).  The decoded tensors are fresh, contiguous, CPU float32 - as the re
 from __future__ import annotations
 
 import json
+import math
 import logging
 import struct
 from typing import Dict, List, Tuple
@@ -121,39 +122,36 @@ class Response:
 
     def encode(self) -> bytes:
         labels = []
-        arrays: List[np.ndarray] = []
+        tensors: List[torch.Tensor] = []
         shapes: List[Tuple[int, ...]] = []
         for node, outs in self.outputs.items():
             for channel, t in outs.items():
                 labels.append({"node": node, "channel": channel})
-                arrays.append(_as_wire_f32(t))
-                shapes.append(tuple(t.shape))
+                tensors.append(t)
+                # a lazily synchronised engine output (engine.PendingTensor) knows its shape without waiting for its copy
+                shapes.append(tuple(getattr(t, "_ivit_shape", None) or t.shape))
 
         json_utf8 = json.dumps(labels).encode()
         body_at = align_next(_HEADER.size + len(json_utf8), 4)
-        total = body_at + sum(8 + 4 * len(s) + 4 * a.size for s, a in zip(shapes, arrays))
+        total = body_at + sum(8 + 4 * len(s) + 4 * math.prod(s) for s in shapes)
         if total > 0xFFFFFFFF:
             raise Exception("response exceeds the 4 GiB the u32 byte_size field can describe")
-
-        out = bytearray(total)  # zero-filled: the pad bytes stay 0 as in the reference
-        _HEADER.pack_into(out, 0, total, RESPONSE_MAGIC, len(arrays), len(json_utf8))
-        out[_HEADER.size:_HEADER.size + len(json_utf8)] = json_utf8
-        pos = body_at
-        view = memoryview(out)
-        for shape, a in zip(shapes, arrays):
-            nd = len(shape)
-            nbytes = 4 * a.size
-            _U32x2.pack_into(out, pos, 8 + 4 * nd + nbytes, nd)
-            struct.pack_into(f"<{nd}I", out, pos + 8, *shape)
-            pos += 8 + 4 * nd
-            if nbytes:
-                view[pos:pos + nbytes] = memoryview(a.reshape(-1)).cast("B")
-            pos += nbytes
-        if not arrays:
+        head = _HEADER.pack(total, RESPONSE_MAGIC, len(tensors), len(json_utf8)) + json_utf8
+        if not tensors:
             # reference quirk (ref :108-109): the pad is a seek past the end that nothing follows, so
             # with zero blocks the pad bytes are never materialised although byte_size counts them
-            return bytes(out[:_HEADER.size + len(json_utf8)])
-        return bytes(out)
+            return head
+        # One pass over the payload: the pieces are joined straight into the bytes object that is returned (no zero-filled
+        # staging buffer, no second copy), and each tensor is only brought to the host form - which waits for its device-to-host
+        # copy if that is still running - when its turn comes, so node k's bytes are collected while node k+1.. still compute.
+        pieces = [head, b"\0" * (body_at - len(head))]
+        for shape, t in zip(shapes, tensors):
+            nd = len(shape)
+            nbytes = 4 * math.prod(shape)
+            pieces.append(_U32x2.pack(8 + 4 * nd + nbytes, nd) + struct.pack(f"<{nd}I", *shape))
+            if nbytes:
+                pieces.append(memoryview(_as_wire_f32(t).reshape(-1)).cast("B"))
+        return b"".join(pieces)
 
 
 def encode_request(nodes: List[dict], edges: List[dict], tensors: List[torch.Tensor]) -> bytes:
