@@ -212,6 +212,7 @@ struct ivit_engine {
     // sequence of a (stage range, batch) is captured once and replayed.  IVIT_GRAPHS=0 disables.
     bool graphs_on = true;
     // LayerNorm fold (bf16 data path; IVIT_FOLD_LN=0 keeps the LayerNorm kernel): see run_layer
+    uint64_t stats_token = 0; int stats_batch = 0;   // resident_token of the host-call output whose LayerNorm statistics pairs / 16-bit copy are in the workspace
     bool fuse_qkv_attn = false;   // IVIT_FUSE_QKV=1, fold path, <= 224 tokens, head dim 64: ivit_qkv_attention_fused (study kernel, off by default)
     bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
     bool fold_blocked = false;      // ivit_ln_fold_calibrate found rows with |mean| / std above its threshold: keep the LayerNorm kernels
@@ -698,10 +699,10 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
     }
     if (!amax4 && fold_for_rows(e, M)) {
         LnFold fold; fold.part = w.ln_part; fold.xb = w.h;
-        fold.stats = stats_in ? nullptr : w.ln_stats;      // finished statistics only where ivit_row_stats made them
-        if (!stats_in) {
+        fold.stats = nullptr;                               // every consumer folds the per-slot pairs, whoever wrote them
+        if (!stats_in) {   // nobody left x's pairs and 16-bit copy behind: the kernel that writes what EPI_BIAS_RESID_STATS would have
             ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * D * 6.0);
-            HIP_TRY(launch_row_stats(xi, D, M, D, w.h, D, w.ln_stats, e->cfg.ln_eps, st, e->f16));
+            HIP_TRY(launch_row_stats(xi, D, M, D, w.h, D, w.ln_part, st, e->f16));
         }
         if (tap == TAP_H1) return 0;
         fold.s = lw.s_in;
@@ -719,7 +720,6 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, xi, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
         if (tap == TAP_PROJ || tap == TAP_H2) return 0;
         fold.s = lw.s_1;
-        fold.stats = nullptr;                               // the out-projection's epilogue left the pairs: fold them in the consumer
         if (run_gemm(e, st, w.h, D, lw.wf_1, M, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "mlp1")) return 1;
         if (tap == TAP_U) return 0;
         if (stats_out) return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_STATS, xo, D, w.x, D, nullptr, 0, 0, 0, 0, &fold, "mlp2");
@@ -754,8 +754,10 @@ static int check_range(ivit_engine* e, int begin, int end, int batch) {
 }
 
 // caller holds e->mu and has set the device
+// `stats_in_first`: the first stage is an encoder layer whose input's statistics pairs and 16-bit copy are already in the workspace
+// (the previous host call left them: forward_host_impl); `leave_stats`: a range that ends on an encoder layer leaves them for the next.
 static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, const float* in, float* out, float* cls_out,
-                       hipStream_t st) {
+                       hipStream_t st, bool stats_in_first = false, bool leave_stats = false) {
     const int L = e->cfg.layers, D = e->D, N = e->N, Np = e->Np;
     const int ST_LN = ST_LAYER0 + L, ST_CLS = ST_LN + 1, ST_HEADS = ST_LN + 2;
     const float* cur = in;
@@ -804,7 +806,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         in_x = true;
         s = ST_LAYER0;
     }
-    bool stats_ready = false;   // LayerNorm fold: the previous layer left x's statistics and bf16 copy behind
+    bool stats_ready = stats_in_first && s == begin && !in_x && fold_for_rows(e, B * N);   // LayerNorm fold: x's statistics pairs and 16-bit copy are in the workspace
     for (; s < end && s < ST_LN; ++s) {
         // the first layer of a range that starts on the caller's tensor reads it in place; the last layer of a range that ends on an
         // encoder layer writes the caller's output (no copies of the stream into / out of w.x)
@@ -812,7 +814,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         in_x = true;
         const bool more = (s + 1 < end) && (s + 1 < ST_LN);
         float* xo = (s + 1 == end) ? out : nullptr;
-        if (run_layer(e, w, st, s - ST_LAYER0, B, nullptr, stats_ready, more, TAP_NONE, xi, xo)) return 1;
+        if (run_layer(e, w, st, s - ST_LAYER0, B, nullptr, stats_ready, more || (leave_stats && s + 1 == end), TAP_NONE, xi, xo)) return 1;
         stats_ready = more && fold_for_rows(e, B * N);
     }
     if (s >= end) return 0;   // the range ended on an encoder layer: its MLP-down GEMM wrote `out`
@@ -850,6 +852,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
 // workspace hand-over between calls on (possibly) different streams; caller holds e->mu
 static int ws_acquire(ivit_engine* e, hipStream_t st) {
     if (e->ws_used) HIP_TRY(hipStreamWaitEvent(st, e->ev_ws, 0));
+    e->stats_token = 0;   // whoever takes the workspaces overwrites the statistics pairs / 16-bit copy a host call may have left
     return 0;
 }
 static int ws_release(ivit_engine* e, hipStream_t st) {
@@ -879,11 +882,11 @@ static Ws ws_slice(ivit_engine* e, int b0) {
 
 // caller holds e->mu and has set the device
 static int forward_locked(ivit_engine* e, int begin, int end, int B, const float* in, float* out, float* cls_out,
-                          hipStream_t st) {
+                          hipStream_t st, bool stats_in_first = false, bool leave_stats = false) {
     if (require_weights(e)) return 1;
     const int L = e->cfg.layers;
     const bool has_layers = (begin < ST_LAYER0 + L) && (end > ST_LAYER0);
-    if (e->split < 2 || B < e->split_min_batch || !has_layers) return forward_one(e, ws_slice(e, 0), begin, end, B, in, out, cls_out, st);
+    if (e->split < 2 || B < e->split_min_batch || !has_layers) return forward_one(e, ws_slice(e, 0), begin, end, B, in, out, cls_out, st, stats_in_first, leave_stats);
     // fork: `split` sub-batches on as many streams; join back into the caller's stream
     const int64_t n_in = shape_elems(&e->cfg, begin, 0), n_out = shape_elems(&e->cfg, end - 1, 1);
     HIP_TRY(hipEventRecord(e->ev_fork, st));
@@ -894,7 +897,7 @@ static int forward_locked(ivit_engine* e, int begin, int end, int B, const float
         hipStream_t s = e->aux_stream[i];
         HIP_TRY(hipStreamWaitEvent(s, e->ev_fork, 0));
         if (forward_one(e, ws_slice(e, b0), begin, end, bn, in + (size_t)b0 * n_in, out + (size_t)b0 * n_out,
-                        cls_out ? cls_out + (size_t)b0 * e->D : nullptr, s)) return 1;
+                        cls_out ? cls_out + (size_t)b0 * e->D : nullptr, s, stats_in_first, leave_stats)) return 1;
         HIP_TRY(hipEventRecord(e->ev_join[i], s));
         b0 += bn;
     }
@@ -943,6 +946,14 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = e->own_stream;
+    const int L = e->cfg.layers;
+    const bool begins_on_layer = stage_begin >= ST_LAYER0 && stage_begin < ST_LAYER0 + L;
+    const bool ends_on_layer = stage_end - 1 >= ST_LAYER0 && stage_end - 1 < ST_LAYER0 + L;
+    const bool folds = e->cfg.precision != IVIT_PRECISION_FP8 && fold_for_rows(e, batch * e->N);
+    // the previous host call ended on an encoder layer and left its output's statistics pairs and 16-bit copy in the workspace
+    // (nothing has touched them since: ws_acquire clears the token), and that output is this call's input: skip ivit_row_stats_pairs
+    const bool chained_stats = in_token != 0 && in_token == e->resident_token && n_in == e->resident_elems &&
+                               e->stats_token == in_token && e->stats_batch == batch && begins_on_layer && folds;
     if (ws_acquire(e, st)) return 1;
     if (in_token != 0 && in_token == e->resident_token && n_in == e->resident_elems) {
         std::swap(e->ext_in, e->ext_out);   // the previous call's output is this call's input: no upload
@@ -955,27 +966,27 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
     }
     if (ext_buffer_writable(e, e->ext_out, st)) return 1;   // the copy of two calls ago may still be reading it
     e->resident_token = 0;                  // ext_out is about to be overwritten
-    const int L = e->cfg.layers;
-    const bool many_launches = (stage_end - stage_begin) > 1 || (stage_begin >= ST_LAYER0 && stage_begin < ST_LAYER0 + L);
+    const bool leave_stats = ends_on_layer && folds;
+    const bool many_launches = (stage_end - stage_begin) > 1 || begins_on_layer;
     const bool use_graph = e->graphs_on && !e->prof_on && batch <= e->graph_max_batch && many_launches;
     bool done = false;
     if (use_graph) {
         if (require_weights(e)) return 1;
-        const auto key = std::make_tuple(stage_begin, stage_end, batch, e->ext_in == e->ext_buf0 ? 0 : 1);
+        const auto key = std::make_tuple(stage_begin, stage_end, batch, (e->ext_in == e->ext_buf0 ? 0 : 1) + (chained_stats ? 2 : 0));
         auto it = e->graphs.find(key);
         if (it == e->graphs.end()) {
             // first request of this shape: run it eagerly (this also performs every one-time
             // hipFuncSetAttribute outside of a capture), then capture the same launch sequence on the
             // engine's own stream for the following requests (nothing in it syncs or allocates)
-            if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
+            if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st, chained_stats, leave_stats)) return 1;
             if (copy_out_async(e, out, e->ext_out, n_out, st)) return 1;
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamSynchronize(st));
             HIP_TRY(hipStreamSynchronize(e->copy_stream));
-            // the capture replays the launches on the same buffers; an encoder layer updates its input
-            // in place only after copying it to the workspace, so ext_in is still intact
+            // the capture records the same launches on the same buffers (nothing executes); an encoder layer reads ext_in
+            // and writes the workspace and ext_out, so ext_in is still intact
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const int rc = forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st);
+            const int rc = forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st, chained_stats, leave_stats);
             const hipError_t ce = hipStreamEndCapture(st, &graph);
             if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
             if (ce != hipSuccess) return fail("hipStreamEndCapture failed: %s", hipGetErrorString(ce));
@@ -989,7 +1000,7 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
             HIP_TRY(hipGraphLaunch(it->second, st));
         }
     } else {
-        if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st)) return 1;
+        if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st, chained_stats, leave_stats)) return 1;
     }
     if (!done && copy_out_async(e, out, e->ext_out, n_out, st)) return 1;
     if (ws_release(e, st)) return 1;
@@ -1002,6 +1013,8 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
     }
     e->resident_token = ++e->token_counter;
     e->resident_elems = n_out;
+    e->stats_token = leave_stats ? e->resident_token : 0;
+    e->stats_batch = batch;
     if (out_token) *out_token = e->resident_token;
     return 0;
 }

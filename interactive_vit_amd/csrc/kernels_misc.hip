@@ -318,53 +318,66 @@ hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, c
     return hipGetLastError();
 }
 
-// Row statistics (mean, rstd) of the residual stream and its bf16 copy, where no GEMM produced the stream (the first
-// layer of a call): what the folded GEMMs read.  One wave per row, two-pass statistics as in ivit_layernorm.
-template <int VPL>
-__global__ __launch_bounds__(256) void ivit_row_stats(const float* __restrict__ x, int ldx, int rows, int dim, bf16_t* __restrict__ xb, int ldxb,
-                                                      float2* __restrict__ stats, float eps, int f16) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int d4 = dim >> 2;
+// Row statistics of the residual stream and its 16-bit copy where no GEMM produced the stream (the first layer of a call): the
+// per-row, per-64-column (sum, M2) pairs and the copy that EPI_BIAS_RESID_STATS leaves behind (gemm_kernel.h:
+// gemm_epilogue_resid_stats), computed in the SAME order - four threads per (row, slot), thread fq summing the column quads
+// j * 16 + fq * 4 .. + 3 (j = 0..3) one after the other from 0, then (s0 + s1) + (s2 + s3); M2 about sum / ncols by explicit fma
+// in that order - so a layer gives the same bits whether its input came out of the previous layer's MLP-down GEMM in the same call,
+// out of an earlier call (chained nodes, which then skip this kernel) or from the caller.
+__global__ __launch_bounds__(256) void ivit_row_stats_pairs(const float* __restrict__ x, int ldx, int rows, int dim, bf16_t* __restrict__ xb, int ldxb,
+                                                            float2* __restrict__ part, int f16) {
+    const int nslots = (dim + 63) >> 6, per_row = nslots * 4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int row = (int)(t / per_row);
+    const int rem = (int)(t - (int64_t)row * per_row), slot = rem >> 2, fq = rem & 3;
+    const bool live = row < rows;
+    if (!live) row = rows - 1;                 // every lane stays for the shuffles
+    const int n_base = slot * 64, ncols = min(64, dim - n_base);
     const float* xr = x + (size_t)row * ldx;
-    float4 v[VPL];
+    float v[4][4];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int c = i * 64 + lane;
-        v[i] = (c < d4) ? reinterpret_cast<const float4*>(xr)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-    const float mean = wave_sum(sum) / (float)dim;
-    float sq = 0.f;
+    for (int j = 0; j < 4; ++j) {
+        const int n = n_base + j * 16 + fq * 4;
+        if (n + 3 < dim) {
+            const float4 q = *reinterpret_cast<const float4*>(xr + n);
+            v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
+        } else {
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int c = i * 64 + lane;
-        if (c < d4) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            sq += (a * a + b * b) + (cc * cc + d * d);
-            u32x2 pk = {pack16x2(f16, v[i].x, v[i].y), pack16x2(f16, v[i].z, v[i].w)};
-            reinterpret_cast<u32x2*>(xb + (size_t)row * ldxb)[c] = pk;
+            for (int r = 0; r < 4; ++r) v[j][r] = (n + r < dim) ? xr[n + r] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < dim) sum += v[j][r];
+        if (live) {
+            bf16_t* ob = xb + (size_t)row * ldxb + n;
+            if (n + 3 < dim) {
+                u32x2 pk = {pack16x2(f16, v[j][0], v[j][1]), pack16x2(f16, v[j][2], v[j][3])};
+                *reinterpret_cast<u32x2*>(ob) = pk;
+            } else {
+                for (int r = 0; r < 4; ++r) if (n + r < dim) ob[r] = enc16(f16, v[j][r]);
+            }
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)dim + eps);
-    if (lane == 0) stats[row] = make_float2(mean, rstd);
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float lmean = ncols > 0 ? sum / (float)ncols : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n_base + j * 16 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < dim) { const float d = v[j][r] - lmean; m2 = fmaf(d, d, m2); }
+    }
+    m2 += __shfl_xor(m2, 1, 64);
+    m2 += __shfl_xor(m2, 2, 64);
+    if (fq == 0 && live && ncols > 0) part[(size_t)row * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
 }
 
-hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* stats, float eps, hipStream_t s, int f16) {
-    if (dim % 4 || dim > 64 * 4 * 8) return hipErrorInvalidValue;
+hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16) {
+    if (dim % 4 || dim > 64 * GEMM_LN_SLOTS) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
-    const dim3 grid(ceil_div(rows, 4)), block(256);
-    const int vpl = ceil_div(dim / 4, 64);
-#define IVIT_RS(V) hipLaunchKernelGGL(ivit_row_stats<V>, grid, block, 0, s, x, ldx, rows, dim, xb, ldxb, stats, eps, f16)
-    if (vpl <= 1) IVIT_RS(1);
-    else if (vpl <= 2) IVIT_RS(2);
-    else if (vpl <= 3) IVIT_RS(3);
-    else if (vpl <= 4) IVIT_RS(4);
-    else if (vpl <= 5) IVIT_RS(5);
-    else IVIT_RS(8);
-#undef IVIT_RS
+    const int64_t threads = (int64_t)rows * ((dim + 63) >> 6) * 4;
+    hipLaunchKernelGGL(ivit_row_stats_pairs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, ldx, rows, dim, xb, ldxb, part, f16);
     return hipGetLastError();
 }
 

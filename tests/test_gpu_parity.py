@@ -349,6 +349,41 @@ def test_host_path_graph_replay_is_bit_identical(small):
         assert torch.equal(other, dev)
 
 
+def test_chained_layer_nodes_reuse_the_statistics_the_previous_node_left(small):
+    """A node chain hands encoder layer k's output to layer k+1 by reference (host path).  Layer k's MLP-down GEMM then leaves the
+    LayerNorm statistics pairs and the 16-bit copy of its output behind (EPI_BIAS_RESID_STATS, as inside a fused range), and layer
+    k+1 skips ivit_row_stats_pairs - which writes the very same pairs, so the bytes do not depend on who made them."""
+    cfg, sd, eng = small
+    if not eng.ln_fold_for(1):
+        pytest.skip("LayerNorm fold off")
+    img = synthetic_images(1, cfg, seed=31)[0]
+    tok = eng.forward(img, 0, 3)                       # transform .. tokens
+    indep = [eng.forward(tok.clone(), 3, 4)]
+    indep.append(eng.forward(indep[0].clone(), 4, 5))
+
+    def stats_launches(fn):
+        eng.profile(True); eng.profile_reset()
+        out = fn()
+        kern = eng.profile_kernels(); eng.profile(False)
+        return out, sum(v["launches"] for k, v in kern.items() if k.startswith("layernorm")), kern
+
+    a, n_a, kern_a = stats_launches(lambda: eng.forward(tok.clone(), 3, 4))
+    assert n_a == 1 and any(k.startswith("mlp2:") and k.endswith("_rs") for k in kern_a), sorted(kern_a)   # leaves the pairs
+    b, n_b, kern_b = stats_launches(lambda: eng.forward(a, 4, 5))                # same object handed on
+    assert n_b == 0, sorted(kern_b)
+    assert torch.equal(a, indep[0]) and torch.equal(b, indep[1])
+    # anything else that takes the workspaces in between invalidates them: the statistics kernel runs again, same bytes
+    a2 = eng.forward(tok.clone(), 3, 4)
+    eng.forward(synthetic_images(1, cfg, seed=32)[0], 0, 2)
+    b2, n_b2, _ = stats_launches(lambda: eng.forward(a2, 4, 5))
+    assert n_b2 == 1 and torch.equal(b2, indep[1])
+    # a modified tensor is uploaded again and gets its own statistics
+    a3 = eng.forward(tok.clone(), 3, 4)
+    a3.mul_(0.5)
+    b3, n_b3, _ = stats_launches(lambda: eng.forward(a3, 4, 5))
+    assert n_b3 == 1 and torch.equal(b3, eng.forward(a3.clone(), 4, 5))
+
+
 def test_chained_host_calls_consume_the_resident_copy(small):
     """Context.compute hands node k's output tensor to node k+1 by reference; the
     engine then continues from the device-resident copy instead of uploading it again

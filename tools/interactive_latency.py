@@ -51,3 +51,21 @@ for it in range(35):
         for name, dt in per: acc.setdefault(name.split(":")[1], []).append(dt)
 med = lambda v: sorted(v)[len(v) // 2] * 1e3
 print("breakdown (ms):", ", ".join(f"{k} {med(v):.3f}" for k, v in acc.items()))
+
+# ---- the same request, asynchronous as compute_bytes runs it: enqueue of all nodes, then where Response.encode waits
+import interactive_vit_amd.message as msg
+acc2 = {"decode": [], "enqueue all nodes": [], "encode: waiting for tensors": [], "encode: join + headers": []}
+orig = msg._as_wire_f32
+for it in range(35):
+    waits = [0.0]
+    def timed(t, _w=waits):
+        a = time.perf_counter(); r = orig(t); _w[0] += time.perf_counter() - a; return r
+    msg._as_wire_f32 = timed
+    t0 = time.perf_counter(); rq = Request(); rq.decode(body); t1 = time.perf_counter()
+    ctx.compute(rq.graph); t2 = time.perf_counter()
+    out = Response(rq.graph).encode(); t3 = time.perf_counter()
+    msg._as_wire_f32 = orig
+    if it >= 5:
+        acc2["decode"].append(t1 - t0); acc2["enqueue all nodes"].append(t2 - t1)
+        acc2["encode: waiting for tensors"].append(waits[0]); acc2["encode: join + headers"].append(t3 - t2 - waits[0])
+print("asynchronous request (ms):", ", ".join(f"{k} {med(v):.3f}" for k, v in acc2.items()))
