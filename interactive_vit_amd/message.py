@@ -17,8 +17,10 @@ SURVEY 3.1).  The decoded tensors are fresh, contiguous, CPU float32 - as the re
 """
 from __future__ import annotations
 
+import ctypes
 import json
 import math
+import sys
 import logging
 import struct
 from typing import Dict, List, Tuple
@@ -108,6 +110,27 @@ def _as_wire_f32(t: torch.Tensor) -> np.ndarray:
     return np.ascontiguousarray(t.detach().numpy())
 
 
+_DIRECT_FILL_MIN = 1 << 20
+
+
+def _writable_bytes(n: int):
+    """A new, uninitialised ``bytes`` object of length n and a writable uint8 view of its payload, or None where that is not
+    available.  CPython's documented way to build a bytes object in place (PyBytes_FromStringAndSize(NULL, n), then fill the
+    buffer PyBytes_AsString returns before anything else sees the object); the view must not outlive the fill."""
+    if sys.implementation.name != "cpython":
+        return None
+    try:
+        new = ctypes.pythonapi.PyBytes_FromStringAndSize
+        new.restype, new.argtypes = ctypes.py_object, [ctypes.c_void_p, ctypes.c_ssize_t]
+        ptr = ctypes.pythonapi.PyBytes_AsString
+        ptr.restype, ptr.argtypes = ctypes.c_void_p, [ctypes.py_object]
+        obj = new(None, n)
+        view = np.ctypeslib.as_array((ctypes.c_ubyte * n).from_address(ptr(obj)))
+        return obj, view
+    except Exception:   # pragma: no cover - exotic builds
+        return None
+
+
 class Response:
     """Collects every output of every node and encodes them (reference :76-127)."""
 
@@ -141,17 +164,38 @@ class Response:
             # reference quirk (ref :108-109): the pad is a seek past the end that nothing follows, so
             # with zero blocks the pad bytes are never materialised although byte_size counts them
             return head
-        # One pass over the payload: the pieces are joined straight into the bytes object that is returned (no zero-filled
-        # staging buffer, no second copy), and each tensor is only brought to the host form - which waits for its device-to-host
-        # copy if that is still running - when its turn comes, so node k's bytes are collected while node k+1.. still compute.
+        # One pass over the payload, and each tensor is only brought to the host form - which waits for its device-to-host copy if
+        # that is still running - when its turn comes, so node k's bytes are collected while nodes k+1.. still compute.
+        # Large responses are written straight into the (not yet shared) bytes object that is returned, so that this copy - 9.7 MB
+        # for a ViT-B/16 chain, 0.4 ms with the page faults of a fresh allocation - also runs while the GPU works; otherwise the
+        # pieces are joined at the end.  Same bytes either way (no zero-filled staging buffer, no second copy in either).
+        fill = _writable_bytes(total) if total >= _DIRECT_FILL_MIN else None
         pieces = [head, b"\0" * (body_at - len(head))]
+        pos = 0
+        if fill is not None:
+            result, view = fill
+            for piece in pieces:
+                view[pos:pos + len(piece)] = np.frombuffer(piece, dtype=np.uint8)
+                pos += len(piece)
         for shape, t in zip(shapes, tensors):
             nd = len(shape)
             nbytes = 4 * math.prod(shape)
-            pieces.append(_U32x2.pack(8 + 4 * nd + nbytes, nd) + struct.pack(f"<{nd}I", *shape))
+            block_head = _U32x2.pack(8 + 4 * nd + nbytes, nd) + struct.pack(f"<{nd}I", *shape)
+            if fill is None:
+                pieces.append(block_head)
+                if nbytes:
+                    pieces.append(memoryview(_as_wire_f32(t).reshape(-1)).cast("B"))
+                continue
+            view[pos:pos + len(block_head)] = np.frombuffer(block_head, dtype=np.uint8)
+            pos += len(block_head)
             if nbytes:
-                pieces.append(memoryview(_as_wire_f32(t).reshape(-1)).cast("B"))
-        return b"".join(pieces)
+                view[pos:pos + nbytes] = _as_wire_f32(t).reshape(-1).view(np.uint8)
+                pos += nbytes
+        if fill is None:
+            return b"".join(pieces)
+        assert pos == total
+        del view
+        return result
 
 
 def encode_request(nodes: List[dict], edges: List[dict], tensors: List[torch.Tensor]) -> bytes:

@@ -29,12 +29,16 @@ def req_fwd():
     return encode_request([{"endpoint": f"{cfg.name}:forward", "params": {}}], [{"tensor": 0, "out_port": {"node": 0, "channel": "o"}}], [img])
 for label, mk in (("node chain (%d nodes, every output returned)" % len(chain), req_chain), ("fused forward node", req_fwd)):
     body = mk()
-    for _ in range(5): st, out = compute_bytes(body, ctx); assert st == 200
+    # warm-up until the host-side pools are populated (page-locked output buffers of 18 nodes x the requests whose responses are
+    # still alive, the allocator's thresholds): the first ~20 requests take 2-9 ms, each new page-locked block is a driver call
+    for _ in range(40): st, out = compute_bytes(body, ctx); assert st == 200
     ts = []
-    for _ in range(30):
+    for _ in range(50):
         t0 = time.perf_counter(); st, out = compute_bytes(body, ctx); ts.append(time.perf_counter() - t0)
+    order_ts = list(ts)
     ts.sort()
-    print(f"{cfg.name} {label}: median {ts[len(ts)//2]*1e3:.2f} ms, p10 {ts[3]*1e3:.2f} ms, request {len(body)/1e6:.2f} MB, response {len(out)/1e6:.2f} MB")
+    print(f"{cfg.name} {label}: median {ts[len(ts)//2]*1e3:.2f} ms, p10 {ts[len(ts)//10]*1e3:.2f} ms, p90 {ts[len(ts)*9//10]*1e3:.2f} ms, request {len(body)/1e6:.2f} MB, response {len(out)/1e6:.2f} MB")
+    print("   in order (ms):", " ".join(f"{t*1e3:.2f}" for t in order_ts))
 
 # ---- where a chain request spends its time (decode / each node / encode), median of 30
 from interactive_vit_amd.message import Request, Response
