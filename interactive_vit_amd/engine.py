@@ -242,10 +242,18 @@ class Engine:
         return self.stages.index(suffix)
 
     def in_shape(self, stage: int) -> Tuple[int, ...]:
-        return stage_shape(self.cfg, stage, 0)
+        return self._stage_shape(stage, 0)
 
     def out_shape(self, stage: int) -> Tuple[int, ...]:
-        return stage_shape(self.cfg, stage, 1)
+        return self._stage_shape(stage, 1)
+
+    def _stage_shape(self, stage: int, which: int) -> Tuple[int, ...]:
+        # the library's table, asked once per stage (two library calls per node call were 10 % of an interactive request's host time)
+        cache = self.__dict__.setdefault("_shape_cache", {})
+        key = (stage, which)
+        if key not in cache:
+            cache[key] = stage_shape(self.cfg, stage, which)
+        return cache[key]
 
     def _split_batch(self, x: torch.Tensor, stage: int) -> Tuple[int, bool]:
         want = self.in_shape(stage)

@@ -93,5 +93,8 @@ def test_bench_gpus_n_starts_its_own_ranks():
     if torch.cuda.is_available():
         pytest.skip("GPU box: covered by tests/test_gpu_distributed.py")
     assert r.returncode != 0
-    assert r.stderr.count("no GPU visible") >= 2, r.stderr[-2000:]
+    # (the launcher ends the other rank as soon as one has failed, so the second message may never be printed: its failure report
+    # names both ranks either way)
+    assert r.stderr.count("no GPU visible") >= 1, r.stderr[-2000:]
+    assert "local_rank: 0" in r.stderr and "local_rank: 1" in r.stderr, r.stderr[-2000:]
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
