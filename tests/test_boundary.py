@@ -64,6 +64,41 @@ def test_order_cycle_raises_instead_of_spinning():
         g.order()
 
 
+def test_order_counter_form_equals_the_plain_rotation_on_random_graphs():
+    """Graph.order keeps a readiness counter per node; the schedule must be the reference's rotation (pop the last, emit if all its
+    producers are done, else move it to the front) - restated here naively and compared on random DAGs, including multi-edges,
+    dangling inputs and nodes listed in any order."""
+    import random
+    from collections import deque
+    from interactive_vit_amd.graph import Graph
+    import torch
+
+    def plain(g):
+        done, emitted, work = set(), [], deque(g.nodes)
+        while work:
+            cand = work.pop()
+            if Graph._ready(cand, done):
+                done.add(cand); emitted.append(cand)
+            else:
+                work.appendleft(cand)
+        return emitted
+
+    rng = random.Random(7)
+    for trial in range(200):
+        n = rng.randint(1, 14)
+        g = Graph()
+        nodes = [g.add_node(f"n{i}", {}) for i in range(n)]
+        rank = list(range(n)); rng.shuffle(rank)          # a hidden topological rank: edges only go up in it
+        for b in range(n):
+            for ch in range(rng.randint(0, 3)):
+                cands = [a for a in range(n) if rank[a] < rank[b]]
+                if cands and rng.random() < 0.8:
+                    g.connect(nodes[rng.choice(cands)], f"o{rng.randint(0, 1)}", nodes[b], f"i{ch}")
+                else:
+                    g.add_input(torch.zeros(1), nodes[b], f"i{ch}")
+        assert [x.index for x in g.order()] == [x.index for x in plain(g)], trial
+
+
 def test_fanout_quirk_preserved():
     g = Graph()
     a, b, c = g.add_node("a", {}), g.add_node("b", {}), g.add_node("c", {})
@@ -89,6 +124,18 @@ def test_wire_bytes_match_reference(case):
     # and the whole handler in one call
     status, out = compute_bytes(body, cos_ctx())
     assert status == 200 and out.hex() == case["response_hex"]
+
+
+@pytest.mark.parametrize("case", GOLD["wire"], ids=lambda c: c["label"])
+def test_wire_bytes_match_reference_when_written_in_place(case, monkeypatch):
+    """Responses of 1 MiB and more are written straight into the bytes object that is returned (message._writable_bytes) instead
+    of being joined from pieces; forced here for the reference's golden cases: same bytes, a real immutable `bytes`."""
+    from interactive_vit_amd import message
+    assert message._writable_bytes(16) is not None, "the in-place path is not available on this interpreter"
+    monkeypatch.setattr(message, "_DIRECT_FILL_MIN", 0)
+    status, out = compute_bytes(bytes.fromhex(case["request_hex"]), cos_ctx())
+    assert status == 200 and type(out) is bytes and out.hex() == case["response_hex"]
+    assert hash(out) == hash(bytes.fromhex(case["response_hex"]))
 
 
 @pytest.mark.parametrize("case", [c for c in GOLD["wire"] if not c["label"].startswith("json_pad_") or c["label"] == "json_pad_0"],
