@@ -386,13 +386,17 @@ def test_config2_vit_b16_batch64_f16_as_dispatched():
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
 
-@pytest.mark.parametrize("model,batch,precision", [("vit_b_16", 64, "bf16"), ("vit_b_16", 3, "bf16"), ("vit_b_16", 9, "f16"), ("vit_ti_16", 17, "bf16"), ("vit_test", 5, "bf16")])
+@pytest.mark.parametrize("model,batch,precision", [("vit_b_16", 64, "bf16"), ("vit_b_16", 3, "bf16"), ("vit_b_16", 9, "f16"), ("vit_ti_16", 17, "bf16"), ("vit_test", 5, "bf16"), ("vit_l_16_224_2layers", 8, "bf16")])
 def test_fused_qkv_attention_is_bit_identical_to_the_two_kernels(model, batch, precision, monkeypatch):
     """ivit_qkv_attention_fused (one workgroup per image and head, q|k|v kept in LDS) against the QKV GEMM + attention
     kernels it replaces: the q|k|v tile it can be asked to store, the attention output and the whole forward, bit for bit."""
     from interactive_vit_amd.engine import Engine
     from interactive_vit_amd.vit_config import test_config
-    cfg = VARIANTS[model] if model in VARIANTS else test_config()
+    if model == "vit_l_16_224_2layers":     # width 1024: 16 statistics slots per row (the fused kernel's second register bank of pairs)
+        from interactive_vit_amd.vit_config import VitConfig
+        cfg = VitConfig(model, 224, 16, 1024, 16, 2, 4096)
+    else:
+        cfg = VARIANTS[model] if model in VARIANTS else test_config()
     sd = init_weights(cfg, seed=0, mode="spec")
     x = synthetic_images(batch, cfg, seed=11)
     tok = oracle_tokens(cfg, sd, x).cuda()
