@@ -167,7 +167,7 @@ struct Ws {
     bf16_t *patches, *h, *qkv, *att, *u, *hc;
     float *x, *clsf;
     unsigned char *h8, *att8, *u8;   // fp8 data path only
-    float2 *ln_part, *ln_stats;      // LayerNorm fold: per-row, per-64-column (sum, M2) pairs; finished (mean, rstd)
+    float2* ln_part;                 // LayerNorm fold: per-row, per-64-column (sum, M2) pairs
 };
 
 struct ivit_engine {
@@ -218,7 +218,7 @@ struct ivit_engine {
     bool fold_blocked = false;      // ivit_ln_fold_calibrate found rows with |mean| / std above its threshold: keep the LayerNorm kernels
     float* ratio_dev = nullptr;     // calibration scratch: max |mean| / std seen (non-null only while calibrating)
     bool ratio_on = false;
-    float2 *ln_part = nullptr, *ln_stats = nullptr;
+    float2* ln_part = nullptr;
     int graph_max_batch = 4;
     std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;   // (begin, end, batch, which buffer is the input)
     // chained host calls: the f32 output of the last host call stays in ext_out; a call that presents that
@@ -388,7 +388,6 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     chk(dev_alloc(e, (void**)&e->u, (size_t)rows_tok * Mlp * 2, true));
     chk(dev_alloc(e, (void**)&e->hc, (size_t)(round_up(B, 256) + 256) * D * 2, true));
     chk(dev_alloc(e, (void**)&e->ln_part, (size_t)rows_tok * GEMM_LN_SLOTS * sizeof(float2), true));
-    chk(dev_alloc(e, (void**)&e->ln_stats, (size_t)rows_tok * sizeof(float2), true));
     if (cfg->precision == IVIT_PRECISION_FP8) {
         e->ld8d = round_up(D, 128); e->ld8m = round_up(Mlp, 128);
         chk(dev_alloc(e, (void**)&e->h8, (size_t)rows_tok * e->ld8d, true));
@@ -669,7 +668,7 @@ static bool fold_for_rows(const ivit_engine* e, int M) {
 // LayerNorm fold (e->fold_ln, the default on the bf16 data path): no LayerNorm kernel and no LayerNorm output
 // tensor.  The GEMM after a LayerNorm multiplies bf16(x) by W . diag(gamma) and its epilogue applies
 // rstd (acc - mean s) + c (kernels.h: EPI_LNFOLD_*); the row statistics and bf16(x) are left behind by the
-// residual GEMM that produced x (EPI_BIAS_RESID_STATS), or by ivit_row_stats where no GEMM did.
+// residual GEMM that produced x (EPI_BIAS_RESID_STATS), or by ivit_row_stats_pairs (the same pairs) where no GEMM did.
 // `stats_in`: x's statistics / bf16 copy already exist (the previous layer's MLP-down GEMM wrote them);
 // `stats_out`: a layer follows in this call, so this layer's MLP-down GEMM writes them for it.
 // `xi` / `xo`: where the layer reads its input stream and leaves its output (default: in place in w.x).  A node that runs one
@@ -876,7 +875,6 @@ static Ws ws_slice(ivit_engine* e, int b0) {
     w.att8 = e->att8 ? e->att8 + rt * e->ld8d : nullptr;
     w.u8 = e->u8 ? e->u8 + rt * e->ld8m : nullptr;
     w.ln_part = e->ln_part + rt * GEMM_LN_SLOTS;
-    w.ln_stats = e->ln_stats + rt;
     return w;
 }
 

@@ -346,7 +346,7 @@ __device__ __forceinline__ void gemm_epilogue_lnfold(const GemmParams& p, f32x4 
 }
 
 // (mean, rstd) of the BM rows of this workgroup's tile -> LDS, one thread per row, at the very start of the kernel
-// (the loads overlap the first operand DMA).  Source: finished statistics (ln_stats: ivit_row_stats wrote them) or the
+// (the loads overlap the first operand DMA).  Source: finished statistics (ln_stats, a kernel-level option the engine no longer uses) or the
 // per-64-column (sum, M2) pairs a residual GEMM left (ln_part), folded in slot order with Chan's formula - exact
 // two-pass statistics, the same bits whatever tile shape wrote the pairs and whichever column tile folds them.
 // Chan's update of a row's running (mean, M2) with the (sum, M2) pair of 64-column slot s2 (callers unroll fully, so s2 and the

@@ -39,7 +39,7 @@ struct GemmParams {
     // EPI_BIAS_RESID_STATS writes ln_part[row][column / 64] and xb; an EPI_LNFOLD_* kernel folds the pairs of its
     // tile's rows in slot order (exact two-pass statistics, independent of who wrote them and when) at its start.
     float2* ln_part;                // EPI_BIAS_RESID_STATS: [rows][GEMM_LN_SLOTS], written
-    const float2* ln_stats;         // EPI_LNFOLD_*: [rows] finished (mean, rstd) (ivit_row_stats), or nullptr: fold ln_part
+    const float2* ln_stats;         // EPI_LNFOLD_*: [rows] finished (mean, rstd), or nullptr (what the engine passes): fold ln_part
     bf16_t* xb; int ldxb;           // EPI_BIAS_RESID_STATS: bf16 copy of the new residual rows
     const float* ln_s;              // EPI_LNFOLD_*: s[n] = sum_k W'[n][k]          (bias = c[n])
     float ln_eps; int ln_dim;       // EPI_LNFOLD_*: LayerNorm epsilon and width (= K of this GEMM)
