@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB_PATH = os.path.join(HERE, "libivit.so")
 SOURCES = ["engine.hip", "kernels_gemm.hip", "kernels_attn.hip", "kernels_misc.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_kernel.h", "gemm256_kernel.h", "gemm256s_kernel.h", "gemmpe_kernel.h",  os.path.join("..", "..", "include", "ivit.h")]
+HEADERS = ["common.h", "kernels.h", "gemm_kernel.h", "gemm256_kernel.h", "gemm256s_kernel.h",  os.path.join("..", "..", "include", "ivit.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

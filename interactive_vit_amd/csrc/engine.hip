@@ -213,7 +213,6 @@ struct ivit_engine {
     bool graphs_on = true;
     // LayerNorm fold (bf16 data path; IVIT_FOLD_LN=0 keeps the LayerNorm kernel): see run_layer
     uint64_t stats_token = 0; int stats_batch = 0;   // resident_token of the host-call output whose LayerNorm statistics pairs / 16-bit copy are in the workspace
-    bool fuse_qkv_attn = false;   // IVIT_FUSE_QKV=1, fold path, <= 224 tokens, head dim 64: ivit_qkv_attention_fused (study kernel, off by default)
     bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
     bool fold_blocked = false;      // ivit_ln_fold_calibrate found rows with |mean| / std above its threshold: keep the LayerNorm kernels
     float* ratio_dev = nullptr;     // calibration scratch: max |mean| / std seen (non-null only while calibrating)
@@ -340,10 +339,6 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         const char* fl = getenv("IVIT_FOLD_LN");
         e->fold_ln = !(fl && atoi(fl) == 0) && cfg->precision != IVIT_PRECISION_FP8 && cfg->dim <= 64 * GEMM_LN_SLOTS;
         e->fold_always = fl && atoi(fl) == 2;
-        const char* fu = getenv("IVIT_FUSE_QKV");
-        // opt-in (IVIT_FUSE_QKV=1): bit-identical to the two kernels it replaces but 9 % slower than them at ViT-B/16 batch 64
-        // (84 us against 53 + 24 us per layer: one workgroup per CU, so its prologue, epilogue and attention phases overlap nothing)
-        e->fuse_qkv_attn = e->fold_ln && fu && atoi(fu) == 1 && fused_qkv_attention_supported(e->N, e->dh, cfg->dim);
         if (e->split < 1 || e->split > ivit_engine::MAX_SPLIT) e->split = 1;
         for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
             if (hipStreamCreateWithFlags(&e->aux_stream[i], hipStreamNonBlocking) != hipSuccess ||
@@ -615,20 +610,6 @@ static int run_attention(ivit_engine* e, const Ws& w, hipStream_t st, int B, uns
     return 0;
 }
 
-static int run_fused_qkv_attention(ivit_engine* e, const Ws& w, hipStream_t st, int B, const LayerWeights& lw, const LnFold& fold, bool store_qkv) {
-    const int D = e->D, M = B * e->N;
-    FusedQkvAttnArgs a{};
-    a.x = w.h; a.ldx = D; a.w = lw.wf_in.p; a.ldw = lw.wf_in.ld; a.c = lw.c_in; a.s = lw.s_in;
-    a.ln_part = fold.stats ? nullptr : fold.part; a.ln_stats = fold.stats; a.ln_eps = e->cfg.ln_eps;
-    a.out = w.att; a.ldo = D; a.qkv_dbg = store_qkv ? w.qkv : nullptr; a.ldq = 3 * D;
-    a.batch = B; a.tokens = e->N; a.heads = e->cfg.heads; a.head_dim = e->dh; a.dim = D; a.rows_total = M; a.f16 = e->f16;
-    a.scale = 1.0f / std::sqrt((float)e->dh);
-    const double flops = 2.0 * M * 3.0 * D * D + 4.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh;
-    ProfScope ps(e, PC_GEMM, st, flops, 2.0 * M * D + 2.0 * 3.0 * D * D + 2.0 * M * D, "qkv+attn", e->f16 ? "ivit_qkv_attention_fused<f16>" : "ivit_qkv_attention_fused<bf16>");
-    HIP_TRY(launch_fused_qkv_attention(a, st));
-    return 0;
-}
-
 // Taps (ivit_debug_layer_tap): a layer is seven steps - 1 LN1 (or the operand copy the QKV GEMM consumes), 2 QKV,
 // 3 attention, 4 out-projection, 5 LN2 (or the operand copy), 6 MLP up, 7 MLP down; `tap` = k stops after step k.
 enum { TAP_NONE = 0, TAP_H1 = 1, TAP_QKV = 2, TAP_ATT = 3, TAP_PROJ = 4, TAP_H2 = 5, TAP_U = 6, TAP_OUT = 7 };
@@ -705,17 +686,10 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         }
         if (tap == TAP_H1) return 0;
         fold.s = lw.s_in;
-        if (e->fuse_qkv_attn) {
-            // QKV projection and attention in one launch, one workgroup per (image, head): q|k|v stays in LDS.  A QKV tap
-            // also stores the tensor (the same values the QKV GEMM would write), so the per-GEMM gates still see it.
-            if (run_fused_qkv_attention(e, w, st, B, lw, fold, tap == TAP_QKV)) return 1;
-            if (tap == TAP_QKV || tap == TAP_ATT) return 0;
-        } else {
-            if (run_gemm(e, st, w.h, D, lw.wf_in, M, lw.c_in, EPI_LNFOLD_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "qkv")) return 1;
-            if (tap == TAP_QKV) return 0;
-            if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
-            if (tap == TAP_ATT) return 0;
-        }
+        if (run_gemm(e, st, w.h, D, lw.wf_in, M, lw.c_in, EPI_LNFOLD_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "qkv")) return 1;
+        if (tap == TAP_QKV) return 0;
+        if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
+        if (tap == TAP_ATT) return 0;
         if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, xi, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
         if (tap == TAP_PROJ || tap == TAP_H2) return 0;
         fold.s = lw.s_1;

@@ -218,8 +218,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // ---- LayerNorm-fold epilogues (their own kernel instantiations: the classic kernels stay as they are).
 // EPI_BIAS_RESID_STATS: residual add as EPI_BIAS_RESID_F32; additionally the bf16 copy of the new rows and, per row,
 // the (sum, M2 about the local mean) of this wave's 64 columns -> ln_part[row][n_base / 64].
+// `pre` (interior patches only): the residual rows of this wave's patch, loaded at the start of the kernel (gemm_body) - the epilogue of a
+// single-round grid is otherwise a load -> add -> store chain at full memory latency for every CU at once (8.4 us of a 33 us launch).
 template <class T, bool INTERIOR, class OP = OpBf16>
-__device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
+__device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
+                                                          const float4 (*pre)[T::FN] = nullptr) {
     static_assert(T::FN * 16 == 64, "one statistics slot per wave column");
     const int slot = n_base >> 6;
     const int ncols = max(0, min(64, p.N - n_base));
@@ -240,7 +243,8 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
 #pragma unroll
         for (int j = 0; j < T::FN; ++j) {
             const int n = n_base + j * 16 + fq * 4;
-            if (INTERIOR || n + 3 < p.N) x[j] = *reinterpret_cast<const float4*>(rs + n);
+            if (INTERIOR && pre) x[j] = pre[i][j];
+            else if (INTERIOR || n + 3 < p.N) x[j] = *reinterpret_cast<const float4*>(rs + n);
             else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int r = 0; r < 4; ++r) if (n + r < p.N) t[r] = rs[n + r]; x[j] = make_float4(t[0], t[1], t[2], t[3]); }
         }
         float sum = 0.f;
@@ -417,12 +421,12 @@ __device__ __forceinline__ void ln_tile_stats_prefetch(const GemmParams& p, int 
 // (One kernel per classic kind was tried too: no gain at the ViT-B shapes, 5-15 % slower at the ViT-H shapes.)
 template <class T, int EK, class OP = OpBf16>
 __device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
-                                                     const float2* tile_stats = nullptr) {
+                                                     const float2* tile_stats = nullptr, const float4 (*pre)[T::FN] = nullptr) {
     const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
-    if (EK == 0) {
+    if constexpr (EK == 0) {
         gemm_epilogue<T, OP>(p, acc, m_base, n_base, fr, fq);
-    } else if (EK == 1) {
-        if (interior) gemm_epilogue_resid_stats<T, true, OP>(p, acc, m_base, n_base, fr, fq);
+    } else if constexpr (EK == 1) {
+        if (interior) gemm_epilogue_resid_stats<T, true, OP>(p, acc, m_base, n_base, fr, fq, pre);
         else gemm_epilogue_resid_stats<T, false, OP>(p, acc, m_base, n_base, fr, fq);
     } else {
         if (interior) gemm_epilogue_lnfold<T, true, OP>(p, acc, m_base, n_base, fr, fq, tile_stats);
@@ -519,10 +523,25 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
         if (ln_deferred) ln_tile_stats_prefetch<T>(p, m0, ln_first);
         else ln_tile_stats<T>(p, m0, tile_stats);                          // visible to every wave after the K loop's barriers
     }
-    IVIT_BODY_STAMP(1);
-
     const int fr = lane & 15;   // fragment row (m for the A^T operand, n for the W operand)
     const int fq = lane >> 4;   // 16-B k-chunk inside a 32-deep MFMA step
+    // EPI_BIAS_RESID_STATS: this wave's residual rows, in flight beside the first operand tiles (retired by the K loop's first wait)
+    float4 rpre[EK == 1 ? T::FM : 1][T::FN];
+    bool have_pre = false;
+    if constexpr (EK == 1) {
+        const int mb = m0 + wr * T::FM * 16, nb = n0 + wc * T::FN * 16;
+        have_pre = nt >= 2 && (mb + T::FM * 16 <= p.M) && (nb + T::FN * 16 <= p.N);   // wave-uniform
+#ifdef IVIT_GEMM_ABLATIONS
+        if (p.order == 3) have_pre = false;   // tools/gemm_bench: IVIT_CFGS=0:0,0:3 times the epilogue-time loads beside it
+#endif
+        if (have_pre) {
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) rpre[i][j] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + i * 16 + fr) * p.ldr + nb + j * 16 + fq * 4);
+        }
+    }
+    IVIT_BODY_STAMP(1);
 
     // one K-tile; FOLD (first iteration of the LayerNorm-fold kernels only, a separate copy of the body so that the loop proper
     // carries neither the branch nor the prefetched registers): fold the prefetched statistics pairs right after the wait
@@ -585,7 +604,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     }
     for (int t = t_first; t < nt; ++t) ktile(t, std::false_type{});
     IVIT_BODY_STAMP(2);
-    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
+    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16,
+                                    (EK == 1 && have_pre) ? rpre : nullptr);
     IVIT_BODY_STAMP(3);
 #ifdef IVIT_GEMM_ABLATIONS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -593,6 +613,71 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     if (p.stamps && threadIdx.x == 0)   // which CU ran this block (per-CU timelines in tools/gemm_bench)
         p.stamps[(size_t)blockIdx.x * 16 + 5] = ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
+}
+
+// ---- single-stage form of gemm_body: ONE operand stage per workgroup (half the LDS), so that THREE workgroups fit a CU.
+// The two-per-CU kernels saturate the CU's L2 -> LDS path (~78 GB/s per CU: 72 one-KiB DMA pieces per 1800 shader cycles, section
+// stamps of tools/gemm_bench) only while BOTH workgroups are inside their K loops; a workgroup in its prologue or epilogue leaves the
+// path to one, which alone keeps it 60 % busy.  With three resident workgroups two are in their loops most of the time (round 3,
+// tools/gemm_bench at M = 12608: qkv 60.1 -> 53.7 us, mlp1 + fold + GELU 80.8 -> 72.5, proj 30.8 -> 30.1, mlp2 69.1 -> 62.5).  Per K-tile:
+// wait + barrier (tile landed), ALL fragments of the K-tile to registers, barrier (everyone has read), restage the same buffer, MFMAs.
+// The DMA round trip is exposed per workgroup and covered by the other two.  Same MFMA order and epilogues as gemm_body: bit-identical
+// (tools/gemm_bench compares bitwise).  Four per CU (fragments read half by half, 128 registers) spills and loses 10-25 %.
+template <class T, bool FP8 = false, int EK = 0, class OP = OpBf16>
+__device__ __forceinline__ void gemm_body_sb(const GemmParams& p, char* smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / T::WAVES_N, wc = wave % T::WAVES_N;
+    int tm, tn;
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
+    const int m0 = tm * T::BM, n0 = tn * T::BN;
+    f32x4 acc[T::FM][T::FN];
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a K-tile is 128 BYTES of every row: 64 bf16 / f16 or 128 fp8
+    constexpr int ESZ = FP8 ? 1 : 2;
+    const size_t lda_b = (size_t)p.lda * ESZ, ldw_b = (size_t)p.ldw * ESZ;
+    const int nt = p.K * ESZ / 128;
+    float2* tile_stats = reinterpret_cast<float2*>(smem + T::STAGE_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
+    if (EK == 2) ln_tile_stats<T>(p, m0, tile_stats);                          // ordinary loads: before any DMA is in flight
+    stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, 0, smem, wave, lane);
+    stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, 0, smem + T::A_BYTES, wave, lane);
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bf16x8 af[T::FM][2], wf[T::FN][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) wf[j][kk] = read_frag(smem + T::A_BYTES, (wc * T::FN + j) * 16 + fr, kk * 4 + fq);
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i) af[i][kk] = read_frag(smem, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();          // every wave holds its fragments: the stage may be overwritten
+        if (t + 1 < nt) {
+            stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, (t + 1) * 128, smem, wave, lane);
+            stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, (t + 1) * 128, smem + T::A_BYTES, wave, lane);
+        }
+        if (FP8) {   // one 128-deep scaled MFMA per fragment pair (see gemm_body)
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) acc[i][j] = mfma_e4m3_16x16x128(wf[j], af[i], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T::FN; ++j) acc[i][j] = OP::mfma(wf[j][kk], af[i][kk], acc[i][j]);
+        }
+    }
+    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
 }
 
 // ---- small-M tile with a deep DMA ring (the interactive path: one to a few images, M = 197 ... ~1000 token rows).

@@ -48,9 +48,14 @@ struct GemmParams {
     int order;                      // microbenchmark builds only: 1 = row bands per XCD (tile_coords_banded), 2 = pairs sharing a CU (gemm_body)
 };
 
-enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_TILE_PE = 8, GEMM_TILE_64D = 9, GEMM_VARIANTS = 10 };
-// GEMM_TILE_PE (gemmpe_kernel.h: persistent 256 x 128, epilogue interleaved into the next tile's main loop) serves the 16-bit-output
-// epilogues only; gemm_pe_supported says whether a call can take it (shape limits, LayerNorm operands as per-slot pairs)
+enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_TILE_PE = 8, GEMM_TILE_64D = 9, GEMM_TILE_P160 = 10, GEMM_TILE_P128 = 11, GEMM_TILE_128W8A = 12, GEMM_TILE_128W8B = 13, GEMM_TILE_160W8 = 14, GEMM_TILE_128SB = 15, GEMM_TILE_160SB = 16, GEMM_VARIANTS = 17 };
+// product variants: GEMM_TILE_128SB / 160SB (one operand stage, three workgroups per CU), GEMM_TILE_256S, GEMM_TILE_64D; the others exist only in
+// microbenchmark builds (IVIT_GEMM_ABLATIONS: two-stage tiles, persistent kernels, eight-wave forms - csrc/study/)
+// GEMM_TILE_P160 / P128 (study/gemmp_kernel.h: persistent two-per-CU workgroups, the finished tile's LayerNorm-fold epilogue drained inside
+// the next tile's main loop) serve EPI_LNFOLD_* only; gemm_persist_supported says whether a call can take them (false in the product build)
+bool gemm_persist_supported(const GemmParams& p);
+// GEMM_TILE_PE (study/gemmpe_kernel.h: persistent 256 x 128, epilogue interleaved into the next tile's main loop) serves the 16-bit-output
+// epilogues only; gemm_pe_supported says whether a call can take it (false in the product build)
 bool gemm_pe_supported(const GemmParams& p);
 // fp8 (e4m3) operands, f32 accumulate: A [M,K] and W [N,K] are BYTE matrices (lda/ldw in elements = bytes)
 hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream);
@@ -79,8 +84,9 @@ struct AttnParams {
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 bool attention_supported(int tokens, int head_dim);
 
+#ifdef IVIT_GEMM_ABLATIONS   // study kernel (csrc/study/fused_qkv_attention.inc), microbenchmark builds only
 // Fused QKV projection (LayerNorm folded) + attention, one workgroup per (image, head), for <= 224 tokens at head dim 64: the
-// q|k|v tensor stays in LDS (kernels_attn.hip: ivit_qkv_attention_fused).  Same values as launch_gemm(EPI_LNFOLD_BF16) followed by
+// q|k|v tensor stays in LDS (ivit_qkv_attention_fused).  Same values as launch_gemm(EPI_LNFOLD_BF16) followed by
 // launch_attention, bit for bit.
 struct FusedQkvAttnArgs {
     const bf16_t* x; int ldx;            // [rows_total, D] 16-bit operand copy of the residual stream
@@ -96,6 +102,7 @@ struct FusedQkvAttnArgs {
 };
 bool fused_qkv_attention_supported(int tokens, int head_dim, int dim);
 hipError_t launch_fused_qkv_attention(const FusedQkvAttnArgs& a, hipStream_t stream);
+#endif
 
 // ---------------------------------------------------------------- misc (kernels_misc.hip)
 // (x - mean[c]) / std[c] on [B,3,S,S] f32

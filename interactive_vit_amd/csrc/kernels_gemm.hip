@@ -1,7 +1,8 @@
-// Instantiations of the bf16 MFMA GEMM template (gemm_kernel.h) and the per-shape tile choice.
+// Instantiations of the 16-bit / fp8 MFMA GEMM templates (gemm_kernel.h, gemm256s_kernel.h) and the per-shape tile choice.
 #include "gemm256s_kernel.h"
-#include "gemmpe_kernel.h"
 #ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost (csrc/study/)
+#include "study/gemmp_kernel.h"
+#include "study/gemmpe_kernel.h"
 #include "study/gemm256p_kernel.h"
 #include "study/gemm256ps_kernel.h"
 #include "study/gemm160x256_kernel.h"
@@ -9,6 +10,7 @@
 #endif
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -17,49 +19,63 @@ namespace ivit {
 
 static int device_cu_count();
 
-using Tile128 = GemmTile<2, 2, 4, 4>;   // 128 x 128, 4 waves (64x64 each), 64 KiB LDS, 2 blocks/CU
-using Tile160 = GemmTile<2, 2, 5, 4>;   // 160 x 128, 4 waves (80x64 each), 72 KiB LDS, 2 blocks/CU
+using Tile128 = GemmTile<2, 2, 4, 4>;   // 128 x 128, 4 waves (64x64 each)
+using Tile160 = GemmTile<2, 2, 5, 4>;   // 160 x 128, 4 waves (80x64 each)
 using Tile256 = GemmTile<2, 4, 8, 4>;   // 256 x 256, 8 waves, plain double buffer (microbenchmark baseline only)
 
-__global__ __launch_bounds__(Tile128::THREADS, 2) void ivit_gemm_bf16_128x128x64(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body<Tile128>(p, smem);
-}
-__global__ __launch_bounds__(Tile160::THREADS, 2) void ivit_gemm_bf16_160x128x64(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body<Tile160>(p, smem);
-}
+// ---- the product tiles for grids of many workgroups: ONE operand stage per workgroup, THREE workgroups per CU (gemm_kernel.h:
+// gemm_body_sb).  Epilogue families: classic (run-time kind), _rs = residual add + 16-bit copy + row statistics for the next GEMM,
+// _lf = LayerNorm applied in the epilogue.
+#define IVIT_SB_KERNEL(NAME, TILE, FP8, EK, OP)                                               \
+    __global__ __launch_bounds__(TILE::THREADS, 3) void NAME(GemmParams p) {                  \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
+        gemm_body_sb<TILE, FP8, EK, OP>(p, smem);                                             \
+    }
+IVIT_SB_KERNEL(ivit_gemm_bf16_128x128x64_sb, Tile128, false, 0, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_bf16_128x128x64_sb_rs, Tile128, false, 1, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_bf16_128x128x64_sb_lf, Tile128, false, 2, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_bf16_160x128x64_sb, Tile160, false, 0, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_bf16_160x128x64_sb_rs, Tile160, false, 1, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_bf16_160x128x64_sb_lf, Tile160, false, 2, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_f16_128x128x64_sb, Tile128, false, 0, OpF16)
+IVIT_SB_KERNEL(ivit_gemm_f16_128x128x64_sb_rs, Tile128, false, 1, OpF16)
+IVIT_SB_KERNEL(ivit_gemm_f16_128x128x64_sb_lf, Tile128, false, 2, OpF16)
+IVIT_SB_KERNEL(ivit_gemm_f16_160x128x64_sb, Tile160, false, 0, OpF16)
+IVIT_SB_KERNEL(ivit_gemm_f16_160x128x64_sb_rs, Tile160, false, 1, OpF16)
+IVIT_SB_KERNEL(ivit_gemm_f16_160x128x64_sb_lf, Tile160, false, 2, OpF16)
+IVIT_SB_KERNEL(ivit_gemm_fp8_128x128x128_sb, Tile128, true, 0, OpBf16)   // e4m3 operands, K-tile of 128 elements
+IVIT_SB_KERNEL(ivit_gemm_fp8_160x128x128_sb, Tile160, true, 0, OpBf16)
+#undef IVIT_SB_KERNEL
 
-// LayerNorm-fold kernel family: the same bodies with their own epilogues.
-// _rs = residual add + bf16 copy + row statistics for the next GEMM; _lf = LayerNorm applied in the epilogue.
-#define IVIT_LNFOLD_KERNEL(NAME, TILE, EK)                                                    \
+// ---- two operand stages, two workgroups per CU (gemm_kernel.h: gemm_body): grids that fit ONE round of its 512 slots (N = D at ViT-B/16:
+// out-projection, MLP down, patch embedding).  In a single round a third workgroup per CU has nothing to overlap with, and in a whole
+// forward these f32-output GEMMs measure 1-4 % faster here than on the single-stage form (tools/libivit_abl.so A/B).
+#define IVIT_2ST_KERNEL(NAME, TILE, EK, OP)                                                   \
     __global__ __launch_bounds__(TILE::THREADS, 2) void NAME(GemmParams p) {                  \
         extern __shared__ __attribute__((aligned(16))) char smem[];                          \
-        gemm_body<TILE, false, EK>(p, smem);                                                  \
+        gemm_body<TILE, false, EK, OP>(p, smem);                                              \
     }
-IVIT_LNFOLD_KERNEL(ivit_gemm_bf16_128x128x64_rs, Tile128, 1)
-IVIT_LNFOLD_KERNEL(ivit_gemm_bf16_128x128x64_lf, Tile128, 2)
-IVIT_LNFOLD_KERNEL(ivit_gemm_bf16_160x128x64_rs, Tile160, 1)
-IVIT_LNFOLD_KERNEL(ivit_gemm_bf16_160x128x64_lf, Tile160, 2)
-#undef IVIT_LNFOLD_KERNEL
-__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag_rs(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm256s_body<0, false, 1>(p, smem);
-}
-__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag_lf(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm256s_body<0, false, 2>(p, smem);
-}
+IVIT_2ST_KERNEL(ivit_gemm_bf16_160x128x64, Tile160, 0, OpBf16)
+IVIT_2ST_KERNEL(ivit_gemm_bf16_160x128x64_rs, Tile160, 1, OpBf16)
+IVIT_2ST_KERNEL(ivit_gemm_bf16_160x128x64_lf, Tile160, 2, OpBf16)
+IVIT_2ST_KERNEL(ivit_gemm_f16_160x128x64, Tile160, 0, OpF16)
+IVIT_2ST_KERNEL(ivit_gemm_f16_160x128x64_rs, Tile160, 1, OpF16)
+IVIT_2ST_KERNEL(ivit_gemm_f16_160x128x64_lf, Tile160, 2, OpF16)
 
-// persistent 256 x 128 tile with the previous tile's epilogue interleaved into the main loop (gemmpe_kernel.h)
-__global__ __launch_bounds__(TilePE::THREADS, 2) void ivit_gemm_bf16_256x128x64_pe(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemmpe_body<OpBf16, false>(p, smem);
-}
-__global__ __launch_bounds__(TilePE::THREADS, 2) void ivit_gemm_bf16_256x128x64_pe_gelu(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemmpe_body<OpBf16, true>(p, smem);
-}
+// ---- 256 x 256 staggered tile, one workgroup per CU: grids with >= 3 rounds of such tiles (ViT-L / ViT-H batches)
+#define IVIT_256S_KERNEL(NAME, FP8, EK, OP)                                                   \
+    __global__ __launch_bounds__(Tile256P::THREADS, 2) void NAME(GemmParams p) {              \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
+        gemm256s_body<0, FP8, EK, OP>(p, smem);                                               \
+    }
+IVIT_256S_KERNEL(ivit_gemm_bf16_256x256x64_stag, false, 0, OpBf16)
+IVIT_256S_KERNEL(ivit_gemm_bf16_256x256x64_stag_rs, false, 1, OpBf16)
+IVIT_256S_KERNEL(ivit_gemm_bf16_256x256x64_stag_lf, false, 2, OpBf16)
+IVIT_256S_KERNEL(ivit_gemm_f16_256x256x64_stag, false, 0, OpF16)
+IVIT_256S_KERNEL(ivit_gemm_f16_256x256x64_stag_rs, false, 1, OpF16)
+IVIT_256S_KERNEL(ivit_gemm_f16_256x256x64_stag_lf, false, 2, OpF16)
+IVIT_256S_KERNEL(ivit_gemm_fp8_256x256x128_stag, true, 0, OpBf16)
+#undef IVIT_256S_KERNEL
 
 // small-M tile with a deep DMA ring (gemm_kernel.h: gemm_body_deep): 64 x 128, 8 waves of 16 x 64 (two per SIMD: one wave's DMA issue
 // and LDS reads run beside its partner's MFMAs), four stages = 96 KiB LDS, one workgroup per CU.  Measured at M = 197 (one image):
@@ -78,41 +94,52 @@ IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_rs, 1, OpF16)
 IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_lf, 2, OpF16)
 #undef IVIT_DEEP_KERNEL
 
-// f16 operands (IVIT_PRECISION_F16): the same bodies on v_mfma_f32_16x16x32_f16 with f16 outputs (same rate as bf16, 11 bits)
-#define IVIT_F16_KERNEL(NAME, THREADS_, BODY)                                                  \
-    __global__ __launch_bounds__(THREADS_, 2) void NAME(GemmParams p) {                        \
-        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
-        BODY;                                                                                  \
-    }
-IVIT_F16_KERNEL(ivit_gemm_f16_128x128x64, Tile128::THREADS, (gemm_body<Tile128, false, 0, OpF16>(p, smem)))
-IVIT_F16_KERNEL(ivit_gemm_f16_128x128x64_rs, Tile128::THREADS, (gemm_body<Tile128, false, 1, OpF16>(p, smem)))
-IVIT_F16_KERNEL(ivit_gemm_f16_128x128x64_lf, Tile128::THREADS, (gemm_body<Tile128, false, 2, OpF16>(p, smem)))
-IVIT_F16_KERNEL(ivit_gemm_f16_160x128x64, Tile160::THREADS, (gemm_body<Tile160, false, 0, OpF16>(p, smem)))
-IVIT_F16_KERNEL(ivit_gemm_f16_160x128x64_rs, Tile160::THREADS, (gemm_body<Tile160, false, 1, OpF16>(p, smem)))
-IVIT_F16_KERNEL(ivit_gemm_f16_160x128x64_lf, Tile160::THREADS, (gemm_body<Tile160, false, 2, OpF16>(p, smem)))
-IVIT_F16_KERNEL(ivit_gemm_f16_256x256x64_stag, Tile256P::THREADS, (gemm256s_body<0, false, 0, OpF16>(p, smem)))
-IVIT_F16_KERNEL(ivit_gemm_f16_256x256x64_stag_rs, Tile256P::THREADS, (gemm256s_body<0, false, 1, OpF16>(p, smem)))
-IVIT_F16_KERNEL(ivit_gemm_f16_256x256x64_stag_lf, Tile256P::THREADS, (gemm256s_body<0, false, 2, OpF16>(p, smem)))
-#undef IVIT_F16_KERNEL
-
-// fp8 (e4m3) operands: same tiles, K-tile of 128 elements, two fp8 MFMA steps per 16-B fragment
-__global__ __launch_bounds__(Tile128::THREADS, 2) void ivit_gemm_fp8_128x128x128(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body<Tile128, true>(p, smem);
-}
-__global__ __launch_bounds__(Tile160::THREADS, 2) void ivit_gemm_fp8_160x128x128(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body<Tile160, true>(p, smem);
-}
-__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_stag(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm256s_body<0>(p, smem);
-}
-__global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_fp8_256x256x128_stag(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm256s_body<0, true>(p, smem);
-}
 #ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost, and timing ablations
+// the two-stage form of the 128 x 128 tile (the 160 x 128 one is a product kernel; it is the bit-identity reference of tools/gemm_bench)
+IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64, Tile128, 0, OpBf16)
+IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64_rs, Tile128, 1, OpBf16)
+IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64_lf, Tile128, 2, OpBf16)
+// persistent two-per-CU workgroups (study/gemmp_kernel.h; round 3): bit-identical, SLOWER (mlp1 + fold + GELU 92.8 us against 80.0; section
+// stamps: profiles/r03a_persist_sections.txt) - IVIT_PERSIST_DUAL 1 = the finished tile's epilogue drained inside the next tile's loop
+#ifndef IVIT_PERSIST_DUAL
+#define IVIT_PERSIST_DUAL true
+#endif
+#define IVIT_PERSIST_KERNEL(NAME, TILE, OP, GELU)                                             \
+    __global__ __launch_bounds__(TILE::THREADS, 2) void NAME(GemmParams p) {                  \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
+        gemm_body_persist_lf<TILE, OP, GELU, IVIT_PERSIST_DUAL>(p, smem);                     \
+    }
+IVIT_PERSIST_KERNEL(ivit_gemm_bf16_160x128x64_plf, Tile160, OpBf16, false)
+IVIT_PERSIST_KERNEL(ivit_gemm_bf16_160x128x64_plf_gelu, Tile160, OpBf16, true)
+IVIT_PERSIST_KERNEL(ivit_gemm_bf16_128x128x64_plf, Tile128, OpBf16, false)
+IVIT_PERSIST_KERNEL(ivit_gemm_bf16_128x128x64_plf_gelu, Tile128, OpBf16, true)
+#undef IVIT_PERSIST_KERNEL
+// eight-wave forms of the two-per-CU tiles (four waves per SIMD, <= 128 registers): -2...-6 % only (the L2 -> LDS path is the limit, not latency hiding)
+using Tile128W8A = GemmTile<2, 4, 4, 2>;   // wave tile 64 x 32
+using Tile128W8B = GemmTile<4, 2, 2, 4>;   // wave tile 32 x 64
+using Tile160W8 = GemmTile<2, 4, 5, 2>;    // wave tile 80 x 32
+#define IVIT_W8_KERNEL(NAME, TILE, EK)                                                        \
+    __global__ __launch_bounds__(TILE::THREADS, 4) void NAME(GemmParams p) {                  \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
+        gemm_body<TILE, false, EK>(p, smem);                                                  \
+    }
+IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8a, Tile128W8A, 0)
+IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8a_lf, Tile128W8A, 2)
+IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8b, Tile128W8B, 0)
+IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8b_lf, Tile128W8B, 2)
+IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8b_rs, Tile128W8B, 1)
+IVIT_W8_KERNEL(ivit_gemm_bf16_160x128x64_w8, Tile160W8, 0)
+IVIT_W8_KERNEL(ivit_gemm_bf16_160x128x64_w8_lf, Tile160W8, 2)
+#undef IVIT_W8_KERNEL
+// persistent 256 x 128 tile with the previous tile's epilogue interleaved into the main loop (study/gemmpe_kernel.h; round 2, ties)
+__global__ __launch_bounds__(TilePE::THREADS, 2) void ivit_gemm_bf16_256x128x64_pe(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemmpe_body<OpBf16, false>(p, smem);
+}
+__global__ __launch_bounds__(TilePE::THREADS, 2) void ivit_gemm_bf16_256x128x64_pe_gelu(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemmpe_body<OpBf16, true>(p, smem);
+}
 // (the 128 x 128 / 160 x 128 tiles on the deep ring of gemm_body_deep, one 4-wave workgroup per CU, were measured too: 87-138 us where the
 // two-stage two-per-CU kernels take 53-77 us - one wave per SIMD cannot cover its own DMA issue)
 __global__ __launch_bounds__(Tile160x256W4::THREADS, 1) void ivit_gemm_bf16_160x256x64_w4(GemmParams p) {
@@ -165,6 +192,13 @@ const char* gemm_variant_name(int v) {
         case GEMM_TILE_256PS: return "ivit_gemm_bf16_256x256x64_persist";
         case GEMM_TILE_PE: return "ivit_gemm_bf16_256x128x64_pe";
         case GEMM_TILE_64D: return "ivit_gemm_bf16_64x128x64_deep";
+        case GEMM_TILE_P160: return "ivit_gemm_bf16_160x128x64_plf";
+        case GEMM_TILE_P128: return "ivit_gemm_bf16_128x128x64_plf";
+        case GEMM_TILE_128W8A: return "ivit_gemm_bf16_128x128x64_w8a";
+        case GEMM_TILE_128W8B: return "ivit_gemm_bf16_128x128x64_w8b";
+        case GEMM_TILE_160W8: return "ivit_gemm_bf16_160x128x64_w8";
+        case GEMM_TILE_128SB: return "ivit_gemm_bf16_128x128x64_sb";
+        case GEMM_TILE_160SB: return "ivit_gemm_bf16_160x128x64_sb";
     }
     return "?";
 }
@@ -182,65 +216,66 @@ hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
     return e;
 }
 
+// one workgroup per output tile; `lds` = the kernel's dynamic LDS (operand stages + BM * 8 bytes of row statistics for the _lf kernels)
 template <class T, class K>
-static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream, int extra_lds = 0) {
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), T::LDS_BYTES + extra_lds);
+static hipError_t launch_grid(K kernel, const GemmParams& p, hipStream_t stream, int lds) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
     if (e != hipSuccess) return e;
     const int tiles = ceil_div(p.M, T::BM) * ceil_div(p.N, T::BN);
 #ifdef IVIT_GEMM_ABLATIONS
     if (p.order == 2) {   // paired order: 512 blocks (some idle), see gemm_body
-        hipLaunchKernelGGL(kernel, dim3(512), dim3(T::THREADS), T::LDS_BYTES + extra_lds, stream, p);
+        hipLaunchKernelGGL(kernel, dim3(512), dim3(T::THREADS), lds, stream, p);
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(T::THREADS), T::LDS_BYTES + extra_lds, stream, p);
+    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(T::THREADS), lds, stream, p);
     return hipGetLastError();
 }
+template <class T, class K>
+static hipError_t launch_tile(K kernel, const GemmParams& p, hipStream_t stream, int extra_lds = 0) { return launch_grid<T>(kernel, p, stream, T::LDS_BYTES + extra_lds); }
+template <class T, class K>
+static hipError_t launch_sb(K kernel, const GemmParams& p, hipStream_t stream, int extra_lds = 0) { return launch_grid<T>(kernel, p, stream, T::STAGE_BYTES + extra_lds); }
 
-// Tile choice, from tools/gemm_bench on MI355X (ViT-B/16 shapes, M = 12608; TFLOP/s with the fused epilogues;
-// profiles/r01f_gemm_microbench.txt, re-checked at the end of the round):
-//                       128x128   160x128   256x256 staggered
-//   N=2304 K= 768 (qkv)    809       784          823
-//   N= 768 K= 768 (proj)   450       534          440        (+ bias + f32 residual)
-//   N=3072 K= 768 (mlp1)   745       744          693        (+ bias + erf-GELU)
-//   N= 768 K=3072 (mlp2)   717       898          785        (+ bias + f32 residual)
-// The tiles differ in FLOP per operand byte (64 / 71 / 128) and in how a grid fills the 256 CUs: 160x128
-// puts 474 tiles on the 512 two-per-CU slots at N = 768 where 128x128 needs two rounds; the 256x256 tile
-// has the K-loop headroom but one workgroup per CU, so its epilogue is not hidden by
-// another workgroup's main loop and its grid quantises worse at this M.  It wins on wide, bf16-output
-// shapes with >= 2 rounds of tiles, and everywhere once a grid has many rounds:
-// On the ViT-L / ViT-H shapes (M = 73856 / 65792 token rows, 4.5+ rounds of 256 x 256 tiles) the
-// staggered 256 x 256 kernel wins every shape by 10-20 % (qkv 1125-1167 vs 929-972 TFLOP/s, mlp2
-// 1122-1131 vs 905-953; hipBLASLt: 1210-1260), so the rule is "enough rounds to amortise the
-// exposed epilogue and the ragged last round".
+// Tile choice, from tools/gemm_bench on MI355X (ViT-B/16 shapes, M = 12608, us per launch with the fused epilogues; round 3,
+// gpurun_out/sb_*.log: two-stage two-per-CU | single-stage three-per-CU | 256 x 256 staggered):
+//                                   128x128  160x128 | 128 sb  160 sb | 256 stag
+//   N=2304 K= 768 qkv  (fold)         60.0     60.1  |  53.8    53.7  |   52.4
+//   N= 768 K= 768 proj (resid+stats)  38.0     30.8  |  35.5    30.1  |   42.1
+//   N=3072 K= 768 mlp1 (fold + GELU)  83.8     80.8  |  77.0    72.5  |   85.5
+//   N= 768 K=3072 mlp2 (resid+stats)  88.1     69.1  |  79.3    62.5  |   83.1
+// The 160 x 128 tile carries 71 FLOP per operand byte against 64 (128 x 128) and quantises best at N = 768 / 3072; the 256 x 256
+// tile (128 FLOP per byte, the K-loop headroom of DESIGN.md section 5) runs one workgroup per CU, so its epilogue is exposed and
+// its grid quantises worse at this M: it wins once a grid has >= 3 rounds of its tiles - on the ViT-L / ViT-H shapes (M = 73856 /
+// 65792 token rows) every shape by 10-20 % over the two-stage 160 x 128 (qkv 1125-1167 vs 929-972 TFLOP/s; hipBLASLt 1210-1260).
 bool gemm_prefers_256(int M, int N, int K) {
-    if (N >= 2048 && N <= 2560 && K <= 1024 && M >= 4096) return true;   // ViT-B QKV-like (1.8 rounds, bf16 out)
+    // ViT-B QKV-like (16-bit output, 1.8 rounds of 256 x 256 tiles): in a whole forward 51.2 us against 53.5 (160 x 128 single-stage) / 56.2 (two-stage)
+    static const int qkv256 = [] { const char* v = getenv("IVIT_QKV_256"); return v ? atoi(v) : 1; }();   // IVIT_QKV_256=0: measurement knob
+    if (qkv256 && N >= 2048 && N <= 2560 && K <= 1024 && M >= 4096) return true;
     const double rounds = (double)ceil_div(M, 256) * ceil_div(N, 256) / 256.0;
     return rounds >= 3.0;
 }
 
 // Small grids (the interactive path: one to a few 197-token images; the classifier head of any batch): when the 64 x 128 tiles of a
-// shape fit one round of one workgroup per CU, every K-tile of the two-stage tiles is a DMA round trip - the deep-ring tile takes
+// shape fit one round of one workgroup per CU, every K-tile of a shallow ring is a DMA round trip - the deep-ring tile takes
 // those (tools/gemm_bench at M = 197: qkv 10.8 -> 7.3 us, proj 13.2 -> 8.1, mlp1 12.1 -> 7.9, mlp2 33.9 -> 19.3; bit-identical).
 int gemm_pick_variant(int M, int N, int K) {
     if (K >= 2 * GEMM_BK && ceil_div(M, Tile64D::BM) * ceil_div(N, Tile64D::BN) <= 256) return GEMM_TILE_64D;
     if (gemm_prefers_256(M, N, K)) return GEMM_TILE_256S;
-    struct Cand { int v, bm, bn; double speed; };
-    static const Cand cands[] = {
-        {GEMM_TILE_160, Tile160::BM, Tile160::BN, 1.03},
-        {GEMM_TILE_128, Tile128::BM, Tile128::BN, 1.00},
-    };
-    int best = GEMM_TILE_160;
-    double best_t = 1e300;
-    for (const Cand& c : cands) {
-        const double tiles = (double)ceil_div(M, c.bm) * ceil_div(N, c.bn);
-        const double rounds = std::ceil(tiles / 512.0);                 // 256 CUs x 2 resident workgroups
-        const double t = rounds * c.bm * c.bn / c.speed;
-        if (t < best_t) { best_t = t; best = c.v; }
-    }
-    return best;
+    // 160 x 128 wherever the grid gives every CU work (fewer operand bytes per FLOP than 128 x 128, and all workgroups of a CU share its
+    // L2 -> LDS path); the smaller tile only for grids below one workgroup per CU.  One round of the two-per-CU slots: the two-stage form;
+    // more: three per CU on one stage.  IVIT_PICK_2STAGE = 0 / 1 forces the single-stage / two-stage form (measurement knob).
+    static const int force = [] { const char* v = getenv("IVIT_PICK_2STAGE"); return v ? atoi(v) : -1; }();
+    const int tiles160 = ceil_div(M, Tile160::BM) * ceil_div(N, Tile160::BN);
+    if (tiles160 < 256) return GEMM_TILE_128SB;
+    if (force >= 0) return force ? GEMM_TILE_160 : GEMM_TILE_160SB;
+    return tiles160 <= 512 ? GEMM_TILE_160 : GEMM_TILE_160SB;
 }
 
+static int device_cu_count() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+}
 
 #ifdef IVIT_GEMM_ABLATIONS
 // persistent kernel: one workgroup per CU (or per tile when there are fewer tiles than CUs)
@@ -253,12 +288,37 @@ static hipError_t launch_persistent(const GemmParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(ivit_gemm_bf16_256x256x64_persist, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, p);
     return hipGetLastError();
 }
-#endif
 
-static int device_cu_count() {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus;
+// ---- persistent LayerNorm-fold kernels (study/gemmp_kernel.h)
+bool gemm_persist_supported(const GemmParams& p) {
+    if (p.epi != EPI_LNFOLD_BF16 && p.epi != EPI_LNFOLD_GELU_BF16) return false;
+    if (p.f16 || p.colscale || p.grp_in || !p.ln_s || !p.ln_part || p.ln_stats) return false;
+    if (p.N % 128 || p.K % GEMM_BK || (p.ldo % 8)) return false;
+    if (p.ln_dim <= 0 || (p.ln_dim % 128) || p.ln_dim > 128 * PERSIST_MAX_F4) return false;
+    if (p.K / GEMM_BK < Tile160::FM + p.ln_dim / 128 + 1) return false;   // slices, then one pair of statistics slots per K-tile
+    if ((unsigned long long)p.M * (unsigned)p.ldo * 2ull >= (1ull << 31)) return false;   // 32-bit buffer offsets of the epilogue stores
+    return true;
+}
+
+template <class T>
+static hipError_t launch_persist_lf(const GemmParams& p, hipStream_t stream) {
+    if (!gemm_persist_supported(p)) return hipErrorInvalidValue;
+    const bool gelu = p.epi == EPI_LNFOLD_GELU_BF16;
+    constexpr bool T160 = std::is_same<T, Tile160>::value;
+    void (*kernel)(GemmParams) = T160 ? (gelu ? ivit_gemm_bf16_160x128x64_plf_gelu : ivit_gemm_bf16_160x128x64_plf) : (gelu ? ivit_gemm_bf16_128x128x64_plf_gelu : ivit_gemm_bf16_128x128x64_plf);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), PersistLds<T>::BYTES);
+    if (e != hipSuccess) return e;
+    const int tiles = ceil_div(p.M, T::BM) * (p.N / T::BN);
+    const int grid = std::min(tiles, 2 * device_cu_count());
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(T::THREADS), PersistLds<T>::BYTES, stream, p);
+    return hipGetLastError();
+}
+
+int gemm_persist_occupancy(int variant) {   // resident workgroups per CU the runtime reports for the bf16 GELU instantiation
+    int n = -1;
+    if (variant == GEMM_TILE_P160) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ivit_gemm_bf16_160x128x64_plf_gelu, Tile160::THREADS, PersistLds<Tile160>::BYTES);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ivit_gemm_bf16_128x128x64_plf_gelu, Tile128::THREADS, PersistLds<Tile128>::BYTES);
+    return n;
 }
 
 bool gemm_pe_supported(const GemmParams& p) {
@@ -290,42 +350,26 @@ static hipError_t launch_pe(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream) {
-    if (p.M <= 0 || p.N <= 0) return hipSuccess;
-    if (p.K <= 0 || p.K % GEMM_BK != 0) return hipErrorInvalidValue;
-    if ((p.lda % 8) || (p.ldw % 8)) return hipErrorInvalidValue;   // 16-B aligned rows for the DMA
-    if ((p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
-    if (variant == GEMM_TILE_PE) return launch_pe(p, stream);
-    const int family = p.epi == EPI_BIAS_RESID_STATS ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
-    if (family) {   // LayerNorm-fold epilogues: their own instantiations of the three product tiles
-        if (p.grp_in != 0) return hipErrorInvalidValue;
-        if (family == 1 && (!p.ln_part || !p.resid || !p.xb || (p.ldxb % 4))) return hipErrorInvalidValue;
-        if (family == 2 && ((!p.ln_stats && !p.ln_part) || !p.ln_s || p.ln_dim <= 0 || p.ln_dim > 64 * GEMM_LN_SLOTS)) return hipErrorInvalidValue;
-    }
-    if (p.f16) {   // f16 operands: the three product tiles, every epilogue family
-        const int extra = family == 2 ? 8 : 0;   // _lf kernels keep (mean, rstd) of their tile's rows in BM * 8 bytes of LDS behind the operand stages
-        switch (variant) {
-            case GEMM_TILE_128: return launch_tile<Tile128>(family == 0 ? ivit_gemm_f16_128x128x64 : family == 1 ? ivit_gemm_f16_128x128x64_rs : ivit_gemm_f16_128x128x64_lf, p, stream, Tile128::BM * extra);
-            case GEMM_TILE_160: return launch_tile<Tile160>(family == 0 ? ivit_gemm_f16_160x128x64 : family == 1 ? ivit_gemm_f16_160x128x64_rs : ivit_gemm_f16_160x128x64_lf, p, stream, Tile160::BM * extra);
-            case GEMM_TILE_256S: return launch_tile<Tile256P>(family == 0 ? ivit_gemm_f16_256x256x64_stag : family == 1 ? ivit_gemm_f16_256x256x64_stag_rs : ivit_gemm_f16_256x256x64_stag_lf, p, stream, Tile256P::BM * extra);
-            case GEMM_TILE_64D: return launch_tile<Tile64D>(family == 0 ? ivit_gemm_f16_64x128x64_deep : family == 1 ? ivit_gemm_f16_64x128x64_deep_rs : ivit_gemm_f16_64x128x64_deep_lf, p, stream, Tile64D::BM * extra);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    if (family) {
-        switch (variant) {   // _lf kernels keep (mean, rstd) of their tile's rows in BM * 8 bytes of LDS behind the operand stages
-            case GEMM_TILE_128: return family == 1 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_rs, p, stream) : launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_lf, p, stream, Tile128::BM * 8);
-            case GEMM_TILE_160: return family == 1 ? launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_rs, p, stream) : launch_tile<Tile160>(ivit_gemm_bf16_160x128x64_lf, p, stream, Tile160::BM * 8);
-            case GEMM_TILE_256S: return family == 1 ? launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_rs, p, stream) : launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag_lf, p, stream, Tile256P::BM * 8);
-            case GEMM_TILE_64D: return family == 1 ? launch_tile<Tile64D>(ivit_gemm_bf16_64x128x64_deep_rs, p, stream) : launch_tile<Tile64D>(ivit_gemm_bf16_64x128x64_deep_lf, p, stream, Tile64D::BM * 8);
-            default: return hipErrorInvalidValue;
-        }
-    }
+// the variants only the microbenchmark can reach; hipErrorNotSupported = not one of them
+static hipError_t launch_study_variant(const GemmParams& p, int variant, int family, hipStream_t stream) {
+    if (p.f16) return hipErrorNotSupported;
     switch (variant) {
-        case GEMM_TILE_64D: return launch_tile<Tile64D>(ivit_gemm_bf16_64x128x64_deep, p, stream);
-        case GEMM_TILE_128: return launch_tile<Tile128>(ivit_gemm_bf16_128x128x64, p, stream);
-        case GEMM_TILE_160: return launch_tile<Tile160>(ivit_gemm_bf16_160x128x64, p, stream);
-#ifdef IVIT_GEMM_ABLATIONS
+        case GEMM_TILE_PE: return launch_pe(p, stream);
+        case GEMM_TILE_P160: return launch_persist_lf<Tile160>(p, stream);
+        case GEMM_TILE_P128: return launch_persist_lf<Tile128>(p, stream);
+        case GEMM_TILE_128:
+            return family == 1 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_rs, p, stream) : family == 2 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_lf, p, stream, Tile128::BM * 8) : launch_tile<Tile128>(ivit_gemm_bf16_128x128x64, p, stream);
+        case GEMM_TILE_128W8A:
+            if (family == 1) return hipErrorInvalidValue;
+            return family == 2 ? launch_tile<Tile128W8A>(ivit_gemm_bf16_128x128x64_w8a_lf, p, stream, Tile128W8A::BM * 8) : launch_tile<Tile128W8A>(ivit_gemm_bf16_128x128x64_w8a, p, stream);
+        case GEMM_TILE_160W8:
+            if (family == 1) return hipErrorInvalidValue;
+            return family == 2 ? launch_tile<Tile160W8>(ivit_gemm_bf16_160x128x64_w8_lf, p, stream, Tile160W8::BM * 8) : launch_tile<Tile160W8>(ivit_gemm_bf16_160x128x64_w8, p, stream);
+        case GEMM_TILE_128W8B:
+            return family == 2 ? launch_tile<Tile128W8B>(ivit_gemm_bf16_128x128x64_w8b_lf, p, stream, Tile128W8B::BM * 8) : family == 1 ? launch_tile<Tile128W8B>(ivit_gemm_bf16_128x128x64_w8b_rs, p, stream) : launch_tile<Tile128W8B>(ivit_gemm_bf16_128x128x64_w8b, p, stream);
+    }
+    if (family) return hipErrorNotSupported;
+    switch (variant) {
         case GEMM_TILE_256: return launch_tile<Tile256>(ivit_gemm_bf16_256x256x64, p, stream);
         case GEMM_TILE_256P:
             if (p.debug == 1) return launch_tile<Tile256P>(ivit_gemm_256pipe_nodma, p, stream);
@@ -336,49 +380,87 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
             return launch_persistent(p, stream);
         case GEMM_TILE_160X256: return launch_tile<Tile160x256>(ivit_gemm_bf16_160x256x64, p, stream);
         case GEMM_TILE_160X256W4: return launch_tile<Tile160x256W4>(ivit_gemm_bf16_160x256x64_w4, p, stream);
-#endif
         case GEMM_TILE_256S:
-#ifdef IVIT_GEMM_ABLATIONS
             if (p.debug == 1) return launch_tile<Tile256P>(ivit_gemm_256stag_nodma, p, stream);
             if (p.debug == 2) return launch_tile<Tile256P>(ivit_gemm_256stag_nomfma, p, stream);
-#endif
-            return launch_tile<Tile256P>(ivit_gemm_bf16_256x256x64_stag, p, stream);
+            break;
     }
+    return hipErrorNotSupported;
+}
+#else
+bool gemm_pe_supported(const GemmParams&) { return false; }
+bool gemm_persist_supported(const GemmParams&) { return false; }
+#endif
+
+hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream) {
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if (p.K <= 0 || p.K % GEMM_BK != 0) return hipErrorInvalidValue;
+    if ((p.lda % 8) || (p.ldw % 8)) return hipErrorInvalidValue;   // 16-B aligned rows for the DMA
+    if ((p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
+    const int family = p.epi == EPI_BIAS_RESID_STATS ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
+    if (family) {   // LayerNorm-fold epilogues: their own instantiations of the product tiles
+        if (p.grp_in != 0) return hipErrorInvalidValue;
+        if (family == 1 && (!p.ln_part || !p.resid || !p.xb || (p.ldxb % 4))) return hipErrorInvalidValue;
+        if (family == 2 && ((!p.ln_stats && !p.ln_part) || !p.ln_s || p.ln_dim <= 0 || p.ln_dim > 64 * GEMM_LN_SLOTS)) return hipErrorInvalidValue;
+    }
+#ifdef IVIT_GEMM_ABLATIONS
+    {
+        const hipError_t e = launch_study_variant(p, variant, family, stream);
+        if (e != hipErrorNotSupported) return e;
+    }
+#endif
+    // _lf kernels keep (mean, rstd) of their tile's rows in BM * 8 bytes of LDS behind the operand stages
+#define IVIT_PICK3(T_, LAUNCH, K0, K1, K2) (family == 0 ? LAUNCH<T_>(K0, p, stream, 0) : family == 1 ? LAUNCH<T_>(K1, p, stream, 0) : LAUNCH<T_>(K2, p, stream, T_::BM * 8))
+    if (p.f16) {
+        switch (variant) {
+            case GEMM_TILE_128SB: return IVIT_PICK3(Tile128, launch_sb, ivit_gemm_f16_128x128x64_sb, ivit_gemm_f16_128x128x64_sb_rs, ivit_gemm_f16_128x128x64_sb_lf);
+            case GEMM_TILE_160SB: return IVIT_PICK3(Tile160, launch_sb, ivit_gemm_f16_160x128x64_sb, ivit_gemm_f16_160x128x64_sb_rs, ivit_gemm_f16_160x128x64_sb_lf);
+            case GEMM_TILE_160: return IVIT_PICK3(Tile160, launch_tile, ivit_gemm_f16_160x128x64, ivit_gemm_f16_160x128x64_rs, ivit_gemm_f16_160x128x64_lf);
+            case GEMM_TILE_256S: return IVIT_PICK3(Tile256P, launch_tile, ivit_gemm_f16_256x256x64_stag, ivit_gemm_f16_256x256x64_stag_rs, ivit_gemm_f16_256x256x64_stag_lf);
+            case GEMM_TILE_64D: return IVIT_PICK3(Tile64D, launch_tile, ivit_gemm_f16_64x128x64_deep, ivit_gemm_f16_64x128x64_deep_rs, ivit_gemm_f16_64x128x64_deep_lf);
+        }
+        return hipErrorInvalidValue;
+    }
+    switch (variant) {
+        case GEMM_TILE_128SB: return IVIT_PICK3(Tile128, launch_sb, ivit_gemm_bf16_128x128x64_sb, ivit_gemm_bf16_128x128x64_sb_rs, ivit_gemm_bf16_128x128x64_sb_lf);
+        case GEMM_TILE_160SB: return IVIT_PICK3(Tile160, launch_sb, ivit_gemm_bf16_160x128x64_sb, ivit_gemm_bf16_160x128x64_sb_rs, ivit_gemm_bf16_160x128x64_sb_lf);
+        case GEMM_TILE_160: return IVIT_PICK3(Tile160, launch_tile, ivit_gemm_bf16_160x128x64, ivit_gemm_bf16_160x128x64_rs, ivit_gemm_bf16_160x128x64_lf);
+        case GEMM_TILE_256S: return IVIT_PICK3(Tile256P, launch_tile, ivit_gemm_bf16_256x256x64_stag, ivit_gemm_bf16_256x256x64_stag_rs, ivit_gemm_bf16_256x256x64_stag_lf);
+        case GEMM_TILE_64D: return IVIT_PICK3(Tile64D, launch_tile, ivit_gemm_bf16_64x128x64_deep, ivit_gemm_bf16_64x128x64_deep_rs, ivit_gemm_bf16_64x128x64_deep_lf);
+    }
+#undef IVIT_PICK3
     return hipErrorInvalidValue;
 }
 
+// fp8 operands: the three-per-CU tiles or the 256 x 256 staggered tile, under the 16-bit rule (no deep-ring form: small fp8 grids take 160 x 128)
 static int fp8_tile(const GemmParams& p) {
-    const double t160 = std::ceil((double)ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) / 512.0) * Tile160::BM / 1.03;
-    const double t128 = std::ceil((double)ceil_div(p.M, Tile128::BM) * ceil_div(p.N, Tile128::BN) / 512.0) * Tile128::BM;
     if (gemm_prefers_256(p.M, p.N, p.K)) return GEMM_TILE_256S;
-    return t160 <= t128 ? GEMM_TILE_160 : GEMM_TILE_128;
+    return ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) >= 256 ? GEMM_TILE_160SB : GEMM_TILE_128SB;
 }
 
 const char* gemm_fp8_kernel_name(const GemmParams& p) {
     switch (fp8_tile(p)) {
         case GEMM_TILE_256S: return "ivit_gemm_fp8_256x256x128_stag";
-        case GEMM_TILE_160: return "ivit_gemm_fp8_160x128x128";
+        case GEMM_TILE_160SB: return "ivit_gemm_fp8_160x128x128_sb";
     }
-    return "ivit_gemm_fp8_128x128x128";
+    return "ivit_gemm_fp8_128x128x128_sb";
 }
 
 const char* gemm_kernel_name(const GemmParams& p) {
     const int v = gemm_pick_variant(p.M, p.N, p.K);
     const int family = p.epi == EPI_BIAS_RESID_STATS ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
-    if (v == GEMM_TILE_64D) {
-        static const char* deep[2][3] = {{"ivit_gemm_bf16_64x128x64_deep", "ivit_gemm_bf16_64x128x64_deep_rs", "ivit_gemm_bf16_64x128x64_deep_lf"},
-                                         {"ivit_gemm_f16_64x128x64_deep", "ivit_gemm_f16_64x128x64_deep_rs", "ivit_gemm_f16_64x128x64_deep_lf"}};
-        return deep[p.f16 ? 1 : 0][family];
-    }
-    static const char* names[3][3] = {
-        {"ivit_gemm_bf16_128x128x64", "ivit_gemm_bf16_128x128x64_rs", "ivit_gemm_bf16_128x128x64_lf"},
-        {"ivit_gemm_bf16_160x128x64", "ivit_gemm_bf16_160x128x64_rs", "ivit_gemm_bf16_160x128x64_lf"},
-        {"ivit_gemm_bf16_256x256x64_stag", "ivit_gemm_bf16_256x256x64_stag_rs", "ivit_gemm_bf16_256x256x64_stag_lf"}};
-    static const char* names16[3][3] = {
-        {"ivit_gemm_f16_128x128x64", "ivit_gemm_f16_128x128x64_rs", "ivit_gemm_f16_128x128x64_lf"},
-        {"ivit_gemm_f16_160x128x64", "ivit_gemm_f16_160x128x64_rs", "ivit_gemm_f16_160x128x64_lf"},
-        {"ivit_gemm_f16_256x256x64_stag", "ivit_gemm_f16_256x256x64_stag_rs", "ivit_gemm_f16_256x256x64_stag_lf"}};
-    return (p.f16 ? names16 : names)[v == GEMM_TILE_128 ? 0 : v == GEMM_TILE_160 ? 1 : 2][family];
+    static const char* names[2][5][3] = {
+        {{"ivit_gemm_bf16_64x128x64_deep", "ivit_gemm_bf16_64x128x64_deep_rs", "ivit_gemm_bf16_64x128x64_deep_lf"},
+         {"ivit_gemm_bf16_128x128x64_sb", "ivit_gemm_bf16_128x128x64_sb_rs", "ivit_gemm_bf16_128x128x64_sb_lf"},
+         {"ivit_gemm_bf16_160x128x64_sb", "ivit_gemm_bf16_160x128x64_sb_rs", "ivit_gemm_bf16_160x128x64_sb_lf"},
+         {"ivit_gemm_bf16_256x256x64_stag", "ivit_gemm_bf16_256x256x64_stag_rs", "ivit_gemm_bf16_256x256x64_stag_lf"},
+         {"ivit_gemm_bf16_160x128x64", "ivit_gemm_bf16_160x128x64_rs", "ivit_gemm_bf16_160x128x64_lf"}},
+        {{"ivit_gemm_f16_64x128x64_deep", "ivit_gemm_f16_64x128x64_deep_rs", "ivit_gemm_f16_64x128x64_deep_lf"},
+         {"ivit_gemm_f16_128x128x64_sb", "ivit_gemm_f16_128x128x64_sb_rs", "ivit_gemm_f16_128x128x64_sb_lf"},
+         {"ivit_gemm_f16_160x128x64_sb", "ivit_gemm_f16_160x128x64_sb_rs", "ivit_gemm_f16_160x128x64_sb_lf"},
+         {"ivit_gemm_f16_256x256x64_stag", "ivit_gemm_f16_256x256x64_stag_rs", "ivit_gemm_f16_256x256x64_stag_lf"},
+         {"ivit_gemm_f16_160x128x64", "ivit_gemm_f16_160x128x64_rs", "ivit_gemm_f16_160x128x64_lf"}}};
+    return names[p.f16 ? 1 : 0][v == GEMM_TILE_64D ? 0 : v == GEMM_TILE_128SB ? 1 : v == GEMM_TILE_160SB ? 2 : v == GEMM_TILE_160 ? 4 : 3][family];
 }
 
 hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
@@ -387,9 +469,9 @@ hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
     if ((p.lda % 16) || (p.ldw % 16) || (p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
     switch (fp8_tile(p)) {
         case GEMM_TILE_256S: return launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag, p, stream);
-        case GEMM_TILE_160: return launch_tile<Tile160>(ivit_gemm_fp8_160x128x128, p, stream);
+        case GEMM_TILE_160SB: return launch_sb<Tile160>(ivit_gemm_fp8_160x128x128_sb, p, stream);
     }
-    return launch_tile<Tile128>(ivit_gemm_fp8_128x128x128, p, stream);
+    return launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb, p, stream);
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {

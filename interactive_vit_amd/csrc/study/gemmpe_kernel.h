@@ -26,7 +26,7 @@
 // Results are bit-identical to the other tile shapes (same MFMA, same K order, same epilogue expressions, the same
 // slot-ordered Chan fold of the row statistics): the batch-independence tests compare across them.
 #pragma once
-#include "gemm_kernel.h"
+#include "../gemm_kernel.h"
 
 namespace ivit {
 

@@ -100,19 +100,54 @@ def token_row(batch_index: int, token: int, tokens: int) -> int:
 # Tests / bench set it from Engine.operand_dtype; the plain (emulate=False) forward never looks at it.
 OPERAND_DTYPE = torch.bfloat16
 
+# Error-budget studies (tools/f16_error_terms.py): when not None, the rounding-aware mode rounds ONLY at the named
+# points - "patch" (unfold image), "w_patch", "x" (the 16-bit copy of the LayerNorm input that the folded GEMMs
+# multiply; the LayerNorm output when unfolded), "w_qkv", "w_mlp1" (W' = W . diag(gamma) of the folded GEMMs), "qkv",
+# "p" (softmax numerators), "att", "w_proj", "gelu", "w_mlp2", "head_in", "w_head".  None (the default, what every
+# test uses) = all of them.
+ROUND_ONLY = None
 
-def rnd(t: torch.Tensor, emulate: bool, dtype=None) -> torch.Tensor:
+# The split-operand GEMMs of the f16 data path (include/ivit.h: ivit_split_gemms): these GEMMs multiply hi + lo pairs of
+# f16 values (x = hi + lo to 22 bits) in three MFMA passes with f32 accumulation - an f32-class product.  A set of names
+# out of {"patch", "head", "proj"}; tests / bench set it from Engine.split_gemms.
+SPLIT_GEMMS = frozenset()
+
+
+def _split(name) -> bool:
+    return name in SPLIT_GEMMS and OPERAND_DTYPE == torch.float16
+
+
+def _on(point) -> bool:
+    return ROUND_ONLY is None or point is None or point in ROUND_ONLY
+
+
+def rnd(t: torch.Tensor, emulate: bool, dtype=None, point=None) -> torch.Tensor:
     """Round-to-nearest-even of an activation to the engine's 16-bit operand type at an engine rounding point
     (emulate mode); ``dtype`` pins the type where the engine's own policy does (bf16 q|k|v on the fp8 path)."""
-    return t.to(torch.float32).to(dtype or OPERAND_DTYPE).to(t.dtype) if emulate else t
+    return t.to(torch.float32).to(dtype or OPERAND_DTYPE).to(t.dtype) if (emulate and _on(point)) else t
 
 
-def _w(sd: Dict[str, torch.Tensor], key: str, dtype, emulate: bool = False) -> torch.Tensor:
+def split16(t: torch.Tensor) -> torch.Tensor:
+    """hi + lo of the engine's split-operand GEMMs: hi = rn16(t), lo = rn16(t - hi), both in the operand type."""
+    t32 = t.to(torch.float32)
+    hi = t32.to(OPERAND_DTYPE).to(torch.float32)
+    lo = (t32 - hi).to(OPERAND_DTYPE).to(torch.float32)
+    return (hi.to(torch.float64) + lo.to(torch.float64)).to(t.dtype)
+
+
+def _w(sd: Dict[str, torch.Tensor], key: str, dtype, emulate: bool = False, point=None) -> torch.Tensor:
     """A parameter in the compute dtype; ``emulate`` rounds it to the operand type first (weight MATRICES only)."""
     w = sd[key]
-    if emulate:
+    if emulate and _on(point):
         w = w.to(torch.float32).to(OPERAND_DTYPE)
     return w.to(dtype)
+
+
+def _w16(sd, key: str, dtype, emulate: bool, point, wsplit: bool) -> torch.Tensor:
+    """A weight matrix as the engine multiplies it: rounded once (``_w``), or hi + lo of a weight-split GEMM."""
+    if emulate and wsplit and _on(point):
+        return split16(sd[key]).to(dtype)
+    return _w(sd, key, dtype, emulate, point)
 
 
 def transform(x: torch.Tensor) -> torch.Tensor:
@@ -148,9 +183,26 @@ def preprocess(x: torch.Tensor, cfg) -> torch.Tensor:
 def conv_proj(x: torch.Tensor, sd, cfg, emulate: bool = False) -> torch.Tensor:
     """Patch embedding as unfold + GEMM: [B,3,S,S] -> [B,Np,D]."""
     dt = x.dtype
-    p = rnd(unfold(x, cfg.image, cfg.patch), emulate)
-    w = _w(sd, "conv_proj.weight", dt, emulate).reshape(cfg.dim, -1)
+    if emulate and _split("patch"):   # three-pass hi/lo product: (hi + lo) of both operands, the lo.lo term dropped
+        p = unfold(x, cfg.image, cfg.patch)
+        w = sd["conv_proj.weight"].to(dt).reshape(cfg.dim, -1)
+        return _split_product(p, w) + _w(sd, "conv_proj.bias", dt)
+    p = rnd(unfold(x, cfg.image, cfg.patch), emulate, point="patch")
+    w = _w(sd, "conv_proj.weight", dt, emulate, "w_patch").reshape(cfg.dim, -1)
     return p @ w.t() + _w(sd, "conv_proj.bias", dt)
+
+
+def _split_product(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """a @ w.T as the engine's three-pass split GEMM evaluates it: a = ah + al, w = wh + wl in the 16-bit operand
+    type; ah.wh + ah.wl + al.wh (the al.wl term, 2^-22 relative, is not computed)."""
+    def hl(t):
+        t32 = t.to(torch.float32)
+        hi = t32.to(OPERAND_DTYPE).to(torch.float32)
+        lo = (t32 - hi).to(OPERAND_DTYPE).to(torch.float32)
+        return hi.to(t.dtype), lo.to(t.dtype)
+    ah, al = hl(a)
+    wh, wl = hl(w)
+    return ah @ wh.t() + (ah @ wl.t() + al @ wh.t())
 
 
 def tokens(t: torch.Tensor, sd, cfg) -> torch.Tensor:
@@ -187,7 +239,7 @@ def attention_core(qkv: torch.Tensor, cfg, emulate: bool = False, p_dtype=None):
     if emulate:
         e = torch.exp(s - s.amax(dim=-1, keepdim=True))
         p = e / e.sum(dim=-1, keepdim=True)
-        a = (rnd(e, True, p_dtype) @ v) / e.sum(dim=-1, keepdim=True)
+        a = (rnd(e, True, p_dtype, point="p") @ v) / e.sum(dim=-1, keepdim=True)
     else:
         p = torch.softmax(s, dim=-1)
         a = p @ v
@@ -197,10 +249,13 @@ def attention_core(qkv: torch.Tensor, cfg, emulate: bool = False, p_dtype=None):
 def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False, emulate: bool = False):
     dt = h.dtype
     pre = layer_prefix(i) + "self_attention."
-    qkv = rnd(h @ _w(sd, pre + "in_proj_weight", dt, emulate).t() + _w(sd, pre + "in_proj_bias", dt), emulate)
+    qkv = rnd(h @ _w(sd, pre + "in_proj_weight", dt, emulate, "w_qkv").t() + _w(sd, pre + "in_proj_bias", dt), emulate, point="qkv")
     a, p = attention_core(qkv, cfg, emulate)
-    a = rnd(a, emulate)
-    out = a @ _w(sd, pre + "out_proj.weight", dt, emulate).t() + _w(sd, pre + "out_proj.bias", dt)
+    if emulate and _split("proj"):
+        out = _split_product(a, sd[pre + "out_proj.weight"].to(dt)) + _w(sd, pre + "out_proj.bias", dt)
+        return (out, p) if return_probs else out
+    a = rnd(a, emulate, point="att")
+    out = a @ _w(sd, pre + "out_proj.weight", dt, emulate, "w_proj").t() + _w(sd, pre + "out_proj.bias", dt)
     return (out, p) if return_probs else out
 
 
@@ -208,7 +263,7 @@ def attention_map(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> to
     """Attention probabilities of layer i for a residual-stream input: [B,N,D] -> [B,H,N,N]."""
     dt = x.dtype
     pre = layer_prefix(i)
-    h = rnd(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), emulate)
+    h = rnd(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), emulate, point="x")
     return attention(h, sd, i, cfg, return_probs=True, emulate=emulate)[1]
 
 
@@ -221,16 +276,34 @@ def attention_map(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> to
 LN_FOLD = False
 
 
-def folded_linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+# How the engine prepares the folded weight W' = W . diag(gamma) (ivit_fold_ln_weights): "twice" = from its 16-bit copy
+# of W, rounded again (bf16 data path, rounds 1-2); "once" = from the f32 matrix the caller handed to ivit_set_weight,
+# one rounding, and c = W beta + b from the f32 matrix too (f16 data path from round 3 on).  Set by tests / bench from
+# Engine.fold_rounding.
+FOLD_ROUNDING = "twice"
+
+
+def folded_linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                  wpoint=None, wsplit: bool = False) -> torch.Tensor:
     """LayerNorm(x) @ w.T + b as the engine's folded GEMM evaluates it (x: [..., D] in the compute dtype)."""
     dt = x.dtype
-    wb = w.to(torch.float32).to(OPERAND_DTYPE).to(dt)                       # the engine's 16-bit copy of W
-    wf = (wb * gamma.to(dt)[None, :]).to(torch.float32).to(OPERAND_DTYPE).to(dt)   # W . diag(gamma), rounded again
+    if not _on(wpoint):
+        wb = w.to(dt)
+        wf = wb * gamma.to(dt)[None, :]
+    elif wsplit:                                  # W' = hi + lo of the f32 product W . gamma (two MFMA passes over the same x)
+        wb = w.to(dt)
+        wf = split16(w.to(torch.float32) * gamma.to(torch.float32)[None, :]).to(dt)
+    elif FOLD_ROUNDING == "once":
+        wb = w.to(dt)
+        wf = (w.to(torch.float32) * gamma.to(torch.float32)[None, :]).to(OPERAND_DTYPE).to(dt)   # f32 product as on the device, one rounding
+    else:
+        wb = w.to(torch.float32).to(OPERAND_DTYPE).to(dt)                       # the engine's 16-bit copy of W
+        wf = (wb * gamma.to(dt)[None, :]).to(torch.float32).to(OPERAND_DTYPE).to(dt)   # W . diag(gamma), rounded again
     s = wf.sum(dim=1)
     c = wb @ beta.to(dt) + b.to(dt)
     mu = x.mean(dim=-1, keepdim=True)
     rstd = 1.0 / torch.sqrt(((x - mu) ** 2).mean(dim=-1, keepdim=True) + eps)
-    xb = x.to(torch.float32).to(OPERAND_DTYPE).to(dt)
+    xb = rnd(x, True, point="x")
     return rstd * (xb @ wf.t() - mu * s) + c
 
 
@@ -240,14 +313,17 @@ def _encoder_layer_fold(x: torch.Tensor, sd, i: int, cfg) -> torch.Tensor:
     b, n, d = x.shape
     hd = cfg.head_dim
     qkv = rnd(folded_linear(x, sd[pre + "self_attention.in_proj_weight"], sd[pre + "self_attention.in_proj_bias"],
-                            sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], cfg.ln_eps), True)
+                            sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], cfg.ln_eps, "w_qkv", _split("qkvw")), True, point="qkv")
     q, k, v = [t.reshape(b, n, cfg.heads, hd).transpose(1, 2) for t in qkv.split(d, dim=-1)]
     sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
     e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
-    a = rnd(((rnd(e, True) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(b, n, d), True)
-    x = x + a @ _w(sd, pre + "self_attention.out_proj.weight", dt, True).t() + _w(sd, pre + "self_attention.out_proj.bias", dt)
-    u = rnd(gelu_erf(folded_linear(x, sd[pre + "mlp.0.weight"], sd[pre + "mlp.0.bias"], sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"], cfg.ln_eps)), True)
-    return x + u @ _w(sd, pre + "mlp.3.weight", dt, True).t() + _w(sd, pre + "mlp.3.bias", dt)
+    a = ((rnd(e, True, point="p") @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(b, n, d)
+    if _split("proj"):
+        x = x + _split_product(a, sd[pre + "self_attention.out_proj.weight"].to(dt)) + _w(sd, pre + "self_attention.out_proj.bias", dt)
+    else:
+        x = x + rnd(a, True, point="att") @ _w(sd, pre + "self_attention.out_proj.weight", dt, True, "w_proj").t() + _w(sd, pre + "self_attention.out_proj.bias", dt)
+    u = rnd(gelu_erf(folded_linear(x, sd[pre + "mlp.0.weight"], sd[pre + "mlp.0.bias"], sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"], cfg.ln_eps, "w_mlp1", _split("mlp1w"))), True, point="gelu")
+    return x + u @ _w16(sd, pre + "mlp.3.weight", dt, True, "w_mlp2", _split("mlp2w")).t() + _w(sd, pre + "mlp.3.bias", dt)
 
 
 def encoder_layer(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> torch.Tensor:
@@ -256,11 +332,11 @@ def encoder_layer(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> to
         return _encoder_layer_fold(x, sd, i, cfg)
     dt = x.dtype
     pre = layer_prefix(i)
-    h = rnd(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), emulate)
+    h = rnd(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), emulate, point="x")
     x = x + attention(h, sd, i, cfg, emulate=emulate)
-    h = rnd(layer_norm(x, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps), emulate)
-    m = rnd(gelu_erf(h @ _w(sd, pre + "mlp.0.weight", dt, emulate).t() + _w(sd, pre + "mlp.0.bias", dt)), emulate)
-    return x + m @ _w(sd, pre + "mlp.3.weight", dt, emulate).t() + _w(sd, pre + "mlp.3.bias", dt)
+    h = rnd(layer_norm(x, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps), emulate, point="x")
+    m = rnd(gelu_erf(h @ _w16(sd, pre + "mlp.0.weight", dt, emulate, "w_mlp1", _split("mlp1w")).t() + _w(sd, pre + "mlp.0.bias", dt)), emulate, point="gelu")
+    return x + m @ _w16(sd, pre + "mlp.3.weight", dt, emulate, "w_mlp2", _split("mlp2w")).t() + _w(sd, pre + "mlp.3.bias", dt)
 
 
 # ---- fp8 data path (BASELINE config 5): the engine's policy restated (include/ivit.h, ivit_fp8_calibrate)
@@ -361,7 +437,9 @@ def cls(x: torch.Tensor) -> torch.Tensor:
 
 def heads(x: torch.Tensor, sd, emulate: bool = False) -> torch.Tensor:
     dt = x.dtype
-    return rnd(x, emulate) @ _w(sd, "heads.head.weight", dt, emulate).t() + _w(sd, "heads.head.bias", dt)
+    if emulate and _split("head"):
+        return _split_product(x, sd["heads.head.weight"].to(dt)) + _w(sd, "heads.head.bias", dt)
+    return rnd(x, emulate, point="head_in") @ _w(sd, "heads.head.weight", dt, emulate, "w_head").t() + _w(sd, "heads.head.bias", dt)
 
 
 def node_suffixes(cfg) -> List[str]:

@@ -42,8 +42,8 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_library_contains_gfx950_code_objects(built_lib):
     data = open(built_lib, "rb").read()
     assert b"gfx950" in data
-    for kernel in (b"ivit_gemm_bf16_128x128x64", b"ivit_gemm_bf16_160x128x64", b"ivit_gemm_bf16_256x256x64_stag",
-                   b"ivit_gemm_fp8_160x128x128", b"ivit_attention_bf16", b"ivit_layernorm", b"ivit_unfold"):
+    for kernel in (b"ivit_gemm_bf16_128x128x64_sb", b"ivit_gemm_bf16_160x128x64_sb", b"ivit_gemm_bf16_160x128x64_rs", b"ivit_gemm_bf16_256x256x64_stag",
+                   b"ivit_gemm_bf16_64x128x64_deep", b"ivit_gemm_fp8_160x128x128_sb", b"ivit_attention_bf16", b"ivit_layernorm", b"ivit_unfold"):
         assert kernel in data, kernel
 
 
