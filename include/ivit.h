@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define IVIT_ABI_VERSION 6
+#define IVIT_ABI_VERSION 7
 
 #define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
 #define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
@@ -47,6 +47,12 @@ extern "C" {
                                    bits: every node within 1e-3 of the PLAIN f32 forward (the reference's sub(x), main/context.py:79-88,
                                    returns f32), where bf16 operand rounding alone costs 2e-3.  Range 6.5e4: meant for LayerNorm-ed
                                    ViT activations; accumulation, statistics and the residual stream stay f32 as in the other modes */
+
+#define IVIT_PRECISION_F16X 3   /* IVIT_PRECISION_F16 with split-operand GEMMs where f16 operand rounding is the larger part of the distance from the
+                                   f32 forward (tools/f16_error_terms.py: the weights are 55 % of it): out-projection on hi + lo pairs of both
+                                   operands (3 MFMA passes), MLP up / down on hi + lo weight pairs (2 passes).  ViT-B/16 logits within 1e-3 of the
+                                   CPU f32 forward over the whole 12-layer chain (7e-4; IVIT_PRECISION_F16: 9e-4 ... 1.2e-3), at ~1.3 x the time.
+                                   Both f16 modes run the patch embedding and the classifier head on hi + lo pairs of both operands (0.7 % of the FLOPs) */
 
 typedef struct ivit_engine ivit_engine;
 

@@ -102,8 +102,8 @@ static bool config_ok(const ivit_config* c, std::string* why) {
     if (c->mlp <= 0 || c->mlp % 64) return bad("mlp must be a positive multiple of 64");
     if (c->layers < 0 || c->classes <= 0 || c->max_batch <= 0) return bad("layers/classes/max_batch out of range");
     if (c->dim > 2048) return bad("dim > 2048 unsupported");
-    if (c->precision != IVIT_PRECISION_BF16 && c->precision != IVIT_PRECISION_FP8 && c->precision != IVIT_PRECISION_F16)
-        return bad("precision must be IVIT_PRECISION_BF16, IVIT_PRECISION_F16 or IVIT_PRECISION_FP8");
+    if (c->precision != IVIT_PRECISION_BF16 && c->precision != IVIT_PRECISION_FP8 && c->precision != IVIT_PRECISION_F16 && c->precision != IVIT_PRECISION_F16X)
+        return bad("precision must be IVIT_PRECISION_BF16, IVIT_PRECISION_F16, IVIT_PRECISION_F16X or IVIT_PRECISION_FP8");
     return true;
 }
 
@@ -140,9 +140,14 @@ extern "C" int64_t ivit_unfold_offset(int32_t image, int32_t patch, int32_t n, i
 enum ProfClass { PC_GEMM = 0, PC_ATTN = 1, PC_LAYERNORM = 2, PC_OTHER = 3, PC_COUNT = 4 };
 static const char* k_prof_names[PC_COUNT] = {"gemm", "attention", "layernorm", "other"};
 
-struct Matrix {   // bf16 [rows_pad][ld], zero padded
+struct Matrix {   // bf16 / f16 [rows_pad][ld], zero padded
     bf16_t* p = nullptr;
     int rows = 0, cols = 0, ld = 0;
+    // split-operand forms (f16 data paths): the row is [hi | hi | lo] (split = 2: the activation operand is a
+    // [hi | lo] pair too) or [hi | lo] (split = 1: one pass over the same activations per part); each part `kpad` columns.
+    int split = 0, kpad = 0;
+    int a_wrap = 0;    // K-tiles of the activation operand before it repeats (GemmParams::a_wrap)
+    float* f32 = nullptr;   // split = 1 matrices that are LayerNorm-folded later (mlp.0): the f32 original, kept for ivit_weights_ready
 };
 struct Matrix8 {  // e4m3 [rows_pad][ld] (ld = round_up(cols, 128) bytes), zero padded, + per-row scales
     unsigned char* p = nullptr;
@@ -173,7 +178,13 @@ struct Ws {
 struct ivit_engine {
     ivit_config cfg{};
     int G = 0, Np = 0, N = 0, K = 0, Kp = 0, D = 0, dh = 0;
-    int f16 = 0;                   // IVIT_PRECISION_F16: every 16-bit tensor of the data path is IEEE f16 instead of bf16
+    int f16 = 0;                   // IVIT_PRECISION_F16 / F16X: every 16-bit tensor of the data path is IEEE f16 instead of bf16
+    // Split-operand GEMMs (hi + lo pairs of f16 values, two or three MFMA passes, f32 accumulation - an f32-class product where the
+    // f16 rounding of an operand is the larger part of a node's distance from the f32 forward; tools/f16_error_terms.py):
+    //   split_ph  (F16 and F16X): patch embedding and classifier head, both operands (0.7 % of the FLOPs);
+    //   f16x      (F16X):         + out-projection (both operands), MLP up and MLP down (weights only).
+    bool split_ph = false, f16x = false;
+    int ld_patch = 0, ld_att = 0, ld_hc = 0;   // row strides of the unfold image / attention output / class-token operand (2 x when they carry [hi | lo])
     std::mutex mu;
     hipStream_t own_stream = nullptr;
     // sub-batch concurrency: memory-bound kernels (LayerNorm, attention staging, GEMM epilogues) of
@@ -268,6 +279,19 @@ static int alloc_matrix(ivit_engine* e, Matrix* m, int rows, int cols) {
     return dev_alloc(e, (void**)&m->p, (size_t)round_up(rows, 256) * m->ld * sizeof(bf16_t), true);
 }
 
+// split != 0: the row holds 3 (split = 2) or 2 (split = 1) parts of round_up(cols, 64) columns
+static int alloc_matrix_split(ivit_engine* e, Matrix* m, int rows, int cols, int split, bool keep_f32 = false) {
+    if (!split) return alloc_matrix(e, m, rows, cols);
+    m->rows = rows;
+    m->cols = cols;
+    m->split = split;
+    m->kpad = round_up(cols, 64);
+    m->ld = (split == 2 ? 3 : 2) * m->kpad;
+    m->a_wrap = (split == 2 ? 2 : 1) * m->kpad / 64;
+    if (dev_alloc(e, (void**)&m->p, (size_t)round_up(rows, 256) * m->ld * sizeof(bf16_t), true)) return 1;
+    return keep_f32 ? dev_alloc(e, (void**)&m->f32, (size_t)rows * cols * sizeof(float), true) : 0;
+}
+
 static int alloc_vec(ivit_engine* e, float** v, int64_t n) { return dev_alloc(e, (void**)v, (size_t)n * sizeof(float), true); }
 
 struct ProfScope {   // brackets one launch with events when profiling is on; `role` / `kernel` name the launch for the per-kernel table
@@ -322,7 +346,15 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     e->G = g; e->Np = g * g; e->N = e->Np + 1; e->D = cfg->dim; e->dh = dh;
     e->K = 3 * cfg->patch * cfg->patch;
     e->Kp = round_up(e->K, 64);
-    e->f16 = cfg->precision == IVIT_PRECISION_F16 ? 1 : 0;
+    e->f16 = (cfg->precision == IVIT_PRECISION_F16 || cfg->precision == IVIT_PRECISION_F16X) ? 1 : 0;
+    e->f16x = cfg->precision == IVIT_PRECISION_F16X;
+    {
+        const char* sp = getenv("IVIT_F16_SPLIT_PATCH_HEAD");   // measurement knob: 0 = the round-2 f16 data path (no split GEMMs)
+        e->split_ph = e->f16 && !(sp && atoi(sp) == 0);
+    }
+    e->ld_patch = (e->split_ph ? 2 : 1) * e->Kp;
+    e->ld_att = (e->f16x ? 2 : 1) * cfg->dim;
+    e->ld_hc = (e->split_ph ? 2 : 1) * cfg->dim;
     const int D = e->D, Mlp = cfg->mlp, B = cfg->max_batch;
     int rc = 0;
     auto chk = [&](int r) { rc |= r; };
@@ -353,7 +385,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
             hipEventCreateWithFlags(&e->ev_buf[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&e->ev_buf[1], hipEventDisableTiming) != hipSuccess) { ivit_destroy(e); return fail("copy stream / event creation failed"); }
     }
-    chk(alloc_matrix(e, &e->w_patch, D, e->K));
+    chk(alloc_matrix_split(e, &e->w_patch, D, e->K, e->split_ph ? 2 : 0));
     chk(alloc_vec(e, &e->b_patch, D));
     chk(alloc_vec(e, &e->cls_tok, D));
     chk(alloc_vec(e, &e->pos, (int64_t)e->N * D));
@@ -362,26 +394,26 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         chk(alloc_vec(e, &lw.ln1_g, D)); chk(alloc_vec(e, &lw.ln1_b, D));
         chk(alloc_vec(e, &lw.ln2_g, D)); chk(alloc_vec(e, &lw.ln2_b, D));
         chk(alloc_matrix(e, &lw.w_in, 3 * D, D)); chk(alloc_vec(e, &lw.b_in, 3 * D));
-        chk(alloc_matrix(e, &lw.w_out, D, D)); chk(alloc_vec(e, &lw.b_out, D));
-        chk(alloc_matrix(e, &lw.w1, Mlp, D)); chk(alloc_vec(e, &lw.b1, Mlp));
-        chk(alloc_matrix(e, &lw.w2, D, Mlp)); chk(alloc_vec(e, &lw.b2, D));
+        chk(alloc_matrix_split(e, &lw.w_out, D, D, e->f16x ? 2 : 0)); chk(alloc_vec(e, &lw.b_out, D));
+        chk(alloc_matrix_split(e, &lw.w1, Mlp, D, e->f16x ? 1 : 0, e->fold_ln)); chk(alloc_vec(e, &lw.b1, Mlp));
+        chk(alloc_matrix_split(e, &lw.w2, D, Mlp, e->f16x ? 1 : 0)); chk(alloc_vec(e, &lw.b2, D));
         if (e->fold_ln) {
             chk(alloc_matrix(e, &lw.wf_in, 3 * D, D)); chk(alloc_vec(e, &lw.s_in, 3 * D)); chk(alloc_vec(e, &lw.c_in, 3 * D));
-            chk(alloc_matrix(e, &lw.wf_1, Mlp, D)); chk(alloc_vec(e, &lw.s_1, Mlp)); chk(alloc_vec(e, &lw.c_1, Mlp));
+            chk(alloc_matrix_split(e, &lw.wf_1, Mlp, D, e->f16x ? 1 : 0)); chk(alloc_vec(e, &lw.s_1, Mlp)); chk(alloc_vec(e, &lw.c_1, Mlp));
         }
         if (rc) break;
     }
     chk(alloc_vec(e, &e->lnf_g, D)); chk(alloc_vec(e, &e->lnf_b, D));
-    chk(alloc_matrix(e, &e->w_head, cfg->classes, D)); chk(alloc_vec(e, &e->b_head, cfg->classes));
+    chk(alloc_matrix_split(e, &e->w_head, cfg->classes, D, e->split_ph ? 2 : 0)); chk(alloc_vec(e, &e->b_head, cfg->classes));
 
     const int64_t rows_tok = round_up(B * e->N, 256) + 256, rows_patch = round_up(B * e->Np, 256) + 256;
-    chk(dev_alloc(e, (void**)&e->patches, (size_t)rows_patch * e->Kp * 2, true));
+    chk(dev_alloc(e, (void**)&e->patches, (size_t)rows_patch * e->ld_patch * 2, true));
     chk(dev_alloc(e, (void**)&e->x, (size_t)rows_tok * D * 4, true));
     chk(dev_alloc(e, (void**)&e->h, (size_t)rows_tok * D * 2, true));
     chk(dev_alloc(e, (void**)&e->qkv, (size_t)rows_tok * 3 * D * 2, true));
-    chk(dev_alloc(e, (void**)&e->att, (size_t)rows_tok * D * 2, true));
+    chk(dev_alloc(e, (void**)&e->att, (size_t)rows_tok * e->ld_att * 2, true));
     chk(dev_alloc(e, (void**)&e->u, (size_t)rows_tok * Mlp * 2, true));
-    chk(dev_alloc(e, (void**)&e->hc, (size_t)(round_up(B, 256) + 256) * D * 2, true));
+    chk(dev_alloc(e, (void**)&e->hc, (size_t)(round_up(B, 256) + 256) * e->ld_hc * 2, true));
     chk(dev_alloc(e, (void**)&e->ln_part, (size_t)rows_tok * GEMM_LN_SLOTS * sizeof(float2), true));
     if (cfg->precision == IVIT_PRECISION_FP8) {
         e->ld8d = round_up(D, 128); e->ld8m = round_up(Mlp, 128);
@@ -505,7 +537,13 @@ extern "C" int ivit_set_weight(ivit_engine* e, const char* name, const float* ho
     } else {
         if (elems > e->upload_elems) return fail("ivit_set_weight: staging buffer too small for '%s'", name);
         HIP_TRY(hipMemcpy(e->upload, host, (size_t)elems * 4, hipMemcpyHostToDevice));
-        HIP_TRY(launch_f32_to_bf16(e->upload, s.cols, s.mat->p, s.mat->ld, s.rows, s.cols, e->own_stream, e->f16));
+        if (s.mat->split) {   // hi / lo pairs straight from the f32 values
+            HIP_TRY(launch_split_weight(e->upload, s.cols, s.rows, s.cols, nullptr, nullptr, nullptr, s.mat->p, s.mat->ld, s.mat->kpad, s.mat->split == 2, nullptr, nullptr,
+                                        e->own_stream, e->f16));
+            if (s.mat->f32) HIP_TRY(hipMemcpyAsync(s.mat->f32, e->upload, (size_t)elems * 4, hipMemcpyDeviceToDevice, e->own_stream));
+        } else {
+            HIP_TRY(launch_f32_to_bf16(e->upload, s.cols, s.mat->p, s.mat->ld, s.rows, s.cols, e->own_stream, e->f16));
+        }
         HIP_TRY(hipStreamSynchronize(e->own_stream));
     }
     e->have[name] = true;
@@ -524,7 +562,10 @@ static int require_weights(ivit_engine* e) {
         hipStream_t st = e->own_stream;
         for (auto& lw : e->layers) {
             HIP_TRY(launch_fold_ln_weights(lw.w_in.p, lw.w_in.ld, lw.w_in.rows, lw.w_in.cols, lw.ln1_g, lw.ln1_b, lw.b_in, lw.wf_in.p, lw.s_in, lw.c_in, st, e->f16));
-            HIP_TRY(launch_fold_ln_weights(lw.w1.p, lw.w1.ld, lw.w1.rows, lw.w1.cols, lw.ln2_g, lw.ln2_b, lw.b1, lw.wf_1.p, lw.s_1, lw.c_1, st, e->f16));
+            if (lw.wf_1.split)   // W' = hi + lo of the f32 product W . gamma; s over hi + lo, c from the f32 matrix
+                HIP_TRY(launch_split_weight(lw.w1.f32, lw.w1.cols, lw.w1.rows, lw.w1.cols, lw.ln2_g, lw.ln2_b, lw.b1, lw.wf_1.p, lw.wf_1.ld, lw.wf_1.kpad, 0, lw.s_1, lw.c_1, st, e->f16));
+            else
+                HIP_TRY(launch_fold_ln_weights(lw.w1.p, lw.w1.ld, lw.w1.rows, lw.w1.cols, lw.ln2_g, lw.ln2_b, lw.b1, lw.wf_1.p, lw.s_1, lw.c_1, st, e->f16));
         }
         HIP_TRY(hipStreamSynchronize(st));
         e->fold_ready = true;
@@ -558,7 +599,7 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
                     int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, const float* rowadd = nullptr,
                     int ldra = 0, int grp_in = 0, int grp_out = 0, int grp_off = 0, const LnFold* lf = nullptr, const char* role = "gemm") {
     GemmParams p{};
-    p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld; p.f16 = e->f16;
+    p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld; p.f16 = e->f16; p.a_wrap = W.a_wrap;
     p.bias = bias; p.epi = epi; p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr;
     p.rowadd = rowadd; p.ldra = ldra; p.grp_in = grp_in; p.grp_out = grp_out; p.grp_off = grp_off;
     if (lf) { p.ln_part = lf->part; p.ln_stats = lf->stats; p.xb = lf->xb; p.ldxb = e->D; p.ln_s = lf->s; p.ln_eps = e->cfg.ln_eps; p.ln_dim = e->D; }
@@ -573,10 +614,11 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
 }
 
 static int run_layernorm(ivit_engine* e, hipStream_t st, const float* x, int64_t row_stride, int rows, const float* g,
-                         const float* b, bf16_t* o16, float* o32, unsigned char* o8 = nullptr, float scale8 = 1.0f) {
+                         const float* b, bf16_t* o16, float* o32, unsigned char* o8 = nullptr, float scale8 = 1.0f, int ldo16 = 0, int lo_off16 = 0) {
     const int D = e->D;
+    if (!ldo16) ldo16 = D;
     ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)rows * D * (4.0 + (o16 ? 2.0 : 0.0) + (o32 ? 4.0 : 0.0) + (o8 ? 1.0 : 0.0)));
-    HIP_TRY(launch_layernorm(x, D, row_stride, rows, D, g, b, e->cfg.ln_eps, o16, D, o32, D, st, o8, e->ld8d, scale8, e->f16));
+    HIP_TRY(launch_layernorm(x, D, row_stride, rows, D, g, b, e->cfg.ln_eps, o16, ldo16, o32, D, st, o8, e->ld8d, scale8, e->f16, lo_off16));
     return 0;
 }
 
@@ -599,7 +641,7 @@ static int run_gemm_fp8(ivit_engine* e, hipStream_t st, const unsigned char* A, 
 static int run_attention(ivit_engine* e, const Ws& w, hipStream_t st, int B, unsigned char* out8, float scale8) {
     const int D = e->D, M = B * e->N;
     AttnParams ap{};
-    ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = D;
+    ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = e->ld_att; ap.lo_off = e->f16x ? D : 0;
     ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh; ap.f16 = e->f16;
     ap.scale = 1.0f / std::sqrt((float)e->dh);
     ap.probs = nullptr;
@@ -667,7 +709,7 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         if (run_layernorm(e, st, xi, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
         if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "qkv")) return 1;
         if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
-        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, xi, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
+        if (run_gemm(e, st, w.att, e->ld_att, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, xi, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
         HIP_TRY(launch_row_mean_ratio(w.x, D, M, D, e->cfg.ln_eps, e->ratio_dev, st));
         if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, w.h, nullptr)) return 1;
         if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "mlp1")) return 1;
@@ -690,7 +732,7 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         if (tap == TAP_QKV) return 0;
         if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
         if (tap == TAP_ATT) return 0;
-        if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, xi, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
+        if (run_gemm(e, st, w.att, e->ld_att, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, xi, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
         if (tap == TAP_PROJ || tap == TAP_H2) return 0;
         fold.s = lw.s_1;
         if (run_gemm(e, st, w.h, D, lw.wf_1, M, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "mlp1")) return 1;
@@ -704,9 +746,9 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
     if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "qkv")) return 1;
     if (tap == TAP_QKV) return 0;
     if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
-    if (amax4) HIP_TRY(launch_amax_bf16(w.att, D, M, D, amax4 + 1, st));
+    if (amax4) HIP_TRY(launch_amax_bf16(w.att, e->ld_att, M, D, amax4 + 1, st));
     if (tap == TAP_ATT) return 0;
-    if (run_gemm(e, st, w.att, D, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, xi, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
+    if (run_gemm(e, st, w.att, e->ld_att, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, xi, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
     if (tap == TAP_PROJ) return 0;
     if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, w.h, nullptr)) return 1;
     if (amax4) HIP_TRY(launch_amax_bf16(w.h, D, M, D, amax4 + 2, st));
@@ -745,7 +787,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         }
         {
             ProfScope ps(e, PC_OTHER, st, 0.0, 4.0 * B * 3 * e->cfg.image * e->cfg.image + 2.0 * B * Np * e->Kp);
-            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 1, st, e->f16));
+            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 1, st, e->f16, e->split_ph));
         }
         patches_ready = true;
         s = ST_CONV;
@@ -753,13 +795,13 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
     if (s == ST_CONV) {
         if (!patches_ready) {
             ProfScope ps(e, PC_OTHER, st, 0.0, 4.0 * B * 3 * e->cfg.image * e->cfg.image + 2.0 * B * Np * e->Kp);
-            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 0, st, e->f16));
+            HIP_TRY(launch_unfold(cur, w.patches, B, e->cfg.image, e->cfg.patch, e->Kp, 0, st, e->f16, e->split_ph));
         }
         if (end == ST_CONV + 1)
-            return run_gemm(e, st, w.patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_F32, out, D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "patch");
+            return run_gemm(e, st, w.patches, e->ld_patch, e->w_patch, B * Np, e->b_patch, EPI_BIAS_F32, out, D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "patch");
         // conv_proj + tokens fused: the GEMM epilogue scatters rows to token 1+n of each image and adds
         // the position embedding; a small kernel writes the class rows
-        if (run_gemm(e, st, w.patches, e->Kp, e->w_patch, B * Np, e->b_patch, EPI_BIAS_ROWADD_F32,
+        if (run_gemm(e, st, w.patches, e->ld_patch, e->w_patch, B * Np, e->b_patch, EPI_BIAS_ROWADD_F32,
                      (end == ST_TOKENS + 1) ? out : w.x, D, nullptr, 0, e->pos, D, Np, N, 1, nullptr, "patch")) return 1;
         {
             ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * D);
@@ -796,12 +838,12 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         if (end == ST_LN + 1) return run_layernorm(e, st, src, 1, B * N, e->lnf_g, e->lnf_b, nullptr, out);
         // only the class rows are consumed downstream: normalise B rows (stride N)
         float* feat = (end == ST_CLS + 1) ? out : (cls_out ? cls_out : w.clsf);
-        if (run_layernorm(e, st, src, N, B, e->lnf_g, e->lnf_b, w.hc, feat)) return 1;
+        if (run_layernorm(e, st, src, N, B, e->lnf_g, e->lnf_b, w.hc, feat, nullptr, 1.0f, e->ld_hc, e->split_ph ? D : 0)) return 1;
         if (end == ST_CLS + 1) {
             if (cls_out) HIP_TRY(hipMemcpyAsync(cls_out, out, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
             return 0;
         }
-        return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "head");
+        return run_gemm(e, st, w.hc, e->ld_hc, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "head");
     }
     if (s == ST_CLS) {
         float* dst = (end == ST_CLS + 1) ? out : w.clsf;
@@ -817,9 +859,10 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
     // heads on an f32 [B,D] input
     {
         ProfScope ps(e, PC_OTHER, st, 0.0, 6.0 * B * D);
-        HIP_TRY(launch_f32_to_bf16(cur, D, w.hc, D, B, D, st, e->f16));
+        if (e->split_ph) HIP_TRY(launch_f32_to_split16(cur, D, w.hc, D, B, D, st, e->f16));
+        else HIP_TRY(launch_f32_to_bf16(cur, D, w.hc, D, B, D, st, e->f16));
     }
-    return run_gemm(e, st, w.hc, D, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "head");
+    return run_gemm(e, st, w.hc, e->ld_hc, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "head");
 }
 
 // workspace hand-over between calls on (possibly) different streams; caller holds e->mu
@@ -837,13 +880,13 @@ static int ws_release(ivit_engine* e, hipStream_t st) {
 static Ws ws_slice(ivit_engine* e, int b0) {
     const size_t rt = (size_t)b0 * e->N, rp = (size_t)b0 * e->Np;
     Ws w;
-    w.patches = e->patches + rp * e->Kp;
+    w.patches = e->patches + rp * e->ld_patch;
     w.x = e->x + rt * e->D;
     w.h = e->h + rt * e->D;
     w.qkv = e->qkv + rt * 3 * e->D;
-    w.att = e->att + rt * e->D;
+    w.att = e->att + rt * e->ld_att;
     w.u = e->u + rt * e->cfg.mlp;
-    w.hc = e->hc + (size_t)b0 * e->D;
+    w.hc = e->hc + (size_t)b0 * e->ld_hc;
     w.clsf = e->clsf + (size_t)b0 * e->D;
     w.h8 = e->h8 ? e->h8 + rt * e->ld8d : nullptr;
     w.att8 = e->att8 ? e->att8 + rt * e->ld8d : nullptr;
@@ -1031,7 +1074,7 @@ static int attention_map_locked(ivit_engine* e, int layer, int B, const float* i
     if (run_layernorm(e, st, in, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
     if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
     AttnParams ap{};
-    ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = D;
+    ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = e->ld_att;
     ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh; ap.f16 = e->f16;
     ap.scale = 1.0f / std::sqrt((float)e->dh);
     ap.probs = out;
@@ -1246,7 +1289,7 @@ extern "C" int ivit_debug_layer_tap(ivit_engine* e, int layer, int batch, const 
     switch (tap) {
         case TAP_H1: case TAP_H2: src = f8 ? (const void*)w.h8 : (const void*)w.h; eb = f8 ? 1 : 2; rb = f8 ? e->ld8d : 2 * D; break;
         case TAP_QKV: src = w.qkv; eb = 2; rb = 2 * 3 * D; break;
-        case TAP_ATT: src = f8 ? (const void*)w.att8 : (const void*)w.att; eb = f8 ? 1 : 2; rb = f8 ? e->ld8d : 2 * D; break;
+        case TAP_ATT: src = f8 ? (const void*)w.att8 : (const void*)w.att; eb = f8 ? 1 : 2; rb = f8 ? e->ld8d : 2 * e->ld_att; break;   // F16X: [hi | lo] per row
         case TAP_U: src = f8 ? (const void*)w.u8 : (const void*)w.u; eb = f8 ? 1 : 2; rb = f8 ? e->ld8m : 2 * Mlp; break;
         default: src = w.x; eb = 4; rb = 4 * D; break;   // TAP_PROJ, TAP_OUT: the f32 residual stream
     }

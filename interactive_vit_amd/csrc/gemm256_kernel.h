@@ -45,6 +45,7 @@ struct G256Ctx {
     const bf16_t* a_src;   // this lane's DMA source for A half-tile h=0, piece i=0, k0=0
     const bf16_t* w_src;   // same for W
     int lda, ldw;
+    int a_wrap;            // GemmParams::a_wrap
     char* smem;
     int wave;
     int a_rd[2];           // per-lane LDS read offsets inside an A half-tile for kk = 0, 1 (mf = 0)
@@ -57,7 +58,9 @@ __device__ __forceinline__ void g256_stage(const G256Ctx& c, int kt, int dst_kt,
     char* dst = c.smem + (dst_kt & 1) * Tile256P::SET_BYTES + (IS_W ? Tile256P::OFF_B0 : Tile256P::OFF_A0) + h * Tile256P::HALF_BYTES;
     if (!IS_W) {
         // piece pc = wave + 8 i  ->  half-tile rows pc*8 .. +8  ->  tile row i*128 + h*64 + wave*8 + r_in
-        const bf16_t* s = c.a_src + (size_t)(h * 64) * c.lda + kt * GEMM_BK;
+        int ka = kt;
+        if (c.a_wrap) { if (ka >= c.a_wrap) ka -= c.a_wrap; if (ka >= c.a_wrap) ka -= c.a_wrap; }
+        const bf16_t* s = c.a_src + (size_t)(h * 64) * c.lda + ka * GEMM_BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((const IVIT_GLOBAL void*)(s + (size_t)(i * 128) * c.lda),

@@ -104,7 +104,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     const int n0 = tn * T::BN;
 
     G256Ctx c;
-    c.smem = smem; c.wave = wave; c.lda = FP8 ? p.lda / 2 : p.lda; c.ldw = FP8 ? p.ldw / 2 : p.ldw;
+    c.smem = smem; c.wave = wave; c.lda = FP8 ? p.lda / 2 : p.lda; c.ldw = FP8 ? p.ldw / 2 : p.ldw; c.a_wrap = p.a_wrap;
     {
         const int r_in = lane >> 3;
         const int chunk = (lane & 7) ^ r_in;

@@ -69,6 +69,15 @@ __device__ __forceinline__ f32x4 mfma_e4m3_16x16x128(const bf16x8 (&w2)[2], cons
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
+// K-tile of A that K-tile t of the product reads (GemmParams::a_wrap: at most three passes over A)
+__device__ __forceinline__ int a_ktile(const GemmParams& p, int t) {
+    if (p.a_wrap) {
+        if (t >= p.a_wrap) t -= p.a_wrap;
+        if (t >= p.a_wrap) t -= p.a_wrap;
+    }
+    return t;
+}
+
 __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int r_local, int q) {
     const int off = r_local * 128 + ((q ^ (r_local & 7)) << 4);
     return *reinterpret_cast<const bf16x8*>(lds_tile + off);
@@ -218,11 +227,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // ---- LayerNorm-fold epilogues (their own kernel instantiations: the classic kernels stay as they are).
 // EPI_BIAS_RESID_STATS: residual add as EPI_BIAS_RESID_F32; additionally the bf16 copy of the new rows and, per row,
 // the (sum, M2 about the local mean) of this wave's 64 columns -> ln_part[row][n_base / 64].
-// `pre` (interior patches only): the residual rows of this wave's patch, loaded at the start of the kernel (gemm_body) - the epilogue of a
-// single-round grid is otherwise a load -> add -> store chain at full memory latency for every CU at once (8.4 us of a 33 us launch).
+// (Round 3: the residual rows loaded at the START of the kernel into 80 registers, so that the epilogue only adds and stores, was measured and
+// removed: vmcnt counts in issue order, so the K loop's first wait also waits for those loads - 38.7 MB from every CU at once, 8 us -
+// and the launch got slower: proj 33 -> 49 us in a forward.)
 template <class T, bool INTERIOR, class OP = OpBf16>
-__device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
-                                                          const float4 (*pre)[T::FN] = nullptr) {
+__device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
     static_assert(T::FN * 16 == 64, "one statistics slot per wave column");
     const int slot = n_base >> 6;
     const int ncols = max(0, min(64, p.N - n_base));
@@ -243,8 +252,7 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
 #pragma unroll
         for (int j = 0; j < T::FN; ++j) {
             const int n = n_base + j * 16 + fq * 4;
-            if (INTERIOR && pre) x[j] = pre[i][j];
-            else if (INTERIOR || n + 3 < p.N) x[j] = *reinterpret_cast<const float4*>(rs + n);
+            if (INTERIOR || n + 3 < p.N) x[j] = *reinterpret_cast<const float4*>(rs + n);
             else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int r = 0; r < 4; ++r) if (n + r < p.N) t[r] = rs[n + r]; x[j] = make_float4(t[0], t[1], t[2], t[3]); }
         }
         float sum = 0.f;
@@ -421,12 +429,12 @@ __device__ __forceinline__ void ln_tile_stats_prefetch(const GemmParams& p, int 
 // (One kernel per classic kind was tried too: no gain at the ViT-B shapes, 5-15 % slower at the ViT-H shapes.)
 template <class T, int EK, class OP = OpBf16>
 __device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
-                                                     const float2* tile_stats = nullptr, const float4 (*pre)[T::FN] = nullptr) {
+                                                     const float2* tile_stats = nullptr) {
     const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
     if constexpr (EK == 0) {
         gemm_epilogue<T, OP>(p, acc, m_base, n_base, fr, fq);
     } else if constexpr (EK == 1) {
-        if (interior) gemm_epilogue_resid_stats<T, true, OP>(p, acc, m_base, n_base, fr, fq, pre);
+        if (interior) gemm_epilogue_resid_stats<T, true, OP>(p, acc, m_base, n_base, fr, fq);
         else gemm_epilogue_resid_stats<T, false, OP>(p, acc, m_base, n_base, fr, fq);
     } else {
         if (interior) gemm_epilogue_lnfold<T, true, OP>(p, acc, m_base, n_base, fr, fq, tile_stats);
@@ -525,22 +533,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     }
     const int fr = lane & 15;   // fragment row (m for the A^T operand, n for the W operand)
     const int fq = lane >> 4;   // 16-B k-chunk inside a 32-deep MFMA step
-    // EPI_BIAS_RESID_STATS: this wave's residual rows, in flight beside the first operand tiles (retired by the K loop's first wait)
-    float4 rpre[EK == 1 ? T::FM : 1][T::FN];
-    bool have_pre = false;
-    if constexpr (EK == 1) {
-        const int mb = m0 + wr * T::FM * 16, nb = n0 + wc * T::FN * 16;
-        have_pre = nt >= 2 && (mb + T::FM * 16 <= p.M) && (nb + T::FN * 16 <= p.N);   // wave-uniform
-#ifdef IVIT_GEMM_ABLATIONS
-        if (p.order == 3) have_pre = false;   // tools/gemm_bench: IVIT_CFGS=0:0,0:3 times the epilogue-time loads beside it
-#endif
-        if (have_pre) {
-#pragma unroll
-            for (int i = 0; i < T::FM; ++i)
-#pragma unroll
-                for (int j = 0; j < T::FN; ++j) rpre[i][j] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + i * 16 + fr) * p.ldr + nb + j * 16 + fq * 4);
-        }
-    }
     IVIT_BODY_STAMP(1);
 
     // one K-tile; FOLD (first iteration of the LayerNorm-fold kernels only, a separate copy of the body so that the loop proper
@@ -557,7 +549,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
         if (FOLD) ln_tile_stats<T>(p, m0, tile_stats, ln_first);
         if (t + 1 < nt) {
             char* nxt = smem + ((t + 1) & 1) * T::STAGE_BYTES;
-            stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, (t + 1) * 128, nxt, wave, lane);
+            stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, a_ktile(p, t + 1) * 128, nxt, wave, lane);
             stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, (t + 1) * 128, nxt + T::A_BYTES, wave, lane);
         }
         const char* a_tile = cur;
@@ -604,8 +596,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     }
     for (int t = t_first; t < nt; ++t) ktile(t, std::false_type{});
     IVIT_BODY_STAMP(2);
-    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16,
-                                    (EK == 1 && have_pre) ? rpre : nullptr);
+    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
     IVIT_BODY_STAMP(3);
 #ifdef IVIT_GEMM_ABLATIONS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -660,7 +651,7 @@ __device__ __forceinline__ void gemm_body_sb(const GemmParams& p, char* smem) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();          // every wave holds its fragments: the stage may be overwritten
         if (t + 1 < nt) {
-            stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, (t + 1) * 128, smem, wave, lane);
+            stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, a_ktile(p, t + 1) * 128, smem, wave, lane);
             stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, (t + 1) * 128, smem + T::A_BYTES, wave, lane);
         }
         if (FP8) {   // one 128-deep scaled MFMA per fragment pair (see gemm_body)
@@ -719,7 +710,7 @@ __device__ __forceinline__ void gemm_body_deep(const GemmParams& p, char* smem) 
     }
     auto stage = [&](int kt, int slot) {
         char* dst = smem + slot * T::STAGE_BYTES;
-        stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, min(kt, last) * 128, dst, wave, lane);
+        stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, a_ktile(p, min(kt, last)) * 128, dst, wave, lane);
         stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, min(kt, last) * 128, dst + T::A_BYTES, wave, lane);
     };
 #pragma unroll

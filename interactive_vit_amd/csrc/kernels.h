@@ -26,6 +26,9 @@ struct GemmParams {
     const bf16_t* A; int lda;     // [M, K] bf16 row-major, rows readable up to round_up(M,256)+256
     const bf16_t* W; int ldw;     // [N, K] bf16 row-major, rows readable up to round_up(N,256)
     int M, N, K;                  // K % 64 == 0 (operands zero-padded); fp8 operands: K % 128 == 0
+    int a_wrap;                   // 0, or the number of 64-deep K-tiles A really has: K-tile t of the product reads A's K-tile t mod a_wrap.
+                                  // Split-operand GEMMs (IVIT_PRECISION_F16X): W = [W_hi | W_hi | W_lo] against A = [A_hi | A_lo] (wraps to A_hi),
+                                  // or W = [W_hi | W_lo] against a single A - hi/lo pairs of f16 values summed in the f32 accumulators
     int f16;                      // 0: A, W and 16-bit outputs are bf16; 1: IEEE f16 (IVIT_PRECISION_F16)
     const float* colscale;        // fp8 operands: acc *= colscale[n] (= activation scale x weight-row scale) before the bias
     float out_scale;              // EPI_BIAS_GELU_FP8: 1 / (scale of the fp8 output tensor)
@@ -77,6 +80,7 @@ struct AttnParams {
     int batch, tokens, heads, head_dim;
     float scale;                   // 1/sqrt(dh)
     int f16;                       // 0: q|k|v, P and the output are bf16; 1: IEEE f16
+    int lo_off;                    // 0, or the element offset from an output value to its low part: out = rn16(O), out[+lo_off] = rn16(O - out)
     float* probs;                  // nullptr, or f32 [B, H, N, N]: write the attention probabilities instead of P.V
     unsigned char* out8; int ldo8; // nullptr, or e4m3 [B*N, D]: write sat_fp8(O * scale8) INSTEAD of the bf16 output
     float scale8;
@@ -110,8 +114,9 @@ hipError_t launch_transform(const float* in, float* out, int batch, int image, h
 // [B,3,H,W] in [0,1] -> [B,3,image,image]: antialiased bilinear resize of the shorter side to `resize`, centre crop, normalise
 hipError_t launch_preprocess(const float* in, int H, int W, float* out, int batch, int image, int resize, hipStream_t s);
 // f32 image -> bf16 unfold matrix [B*Np, kpad] (columns >= 3p^2 zero); normalise fuses the transform
+// split: rows are [hi | lo] of 2 * kpad columns (hi = rn16(x), lo = rn16(x - hi)) for the split-operand patch GEMM
 hipError_t launch_unfold(const float* in, bf16_t* out, int batch, int image, int patch, int kpad,
-                         int normalise, hipStream_t s, int f16 = 0);
+                         int normalise, hipStream_t s, int f16 = 0, int split = 0);
 // out[b,0,:] = cls + pos[0]; out[b,1+n,:] = in[b,n,:] + pos[1+n]   (in == nullptr: class rows only)
 hipError_t launch_tokens(const float* in, const float* cls, const float* pos, float* out, int batch,
                          int patches, int dim, hipStream_t s);
@@ -120,7 +125,8 @@ hipError_t launch_tokens(const float* in, const float* cls, const float* pos, fl
 // optional third output: e4m3 (out_fp8, ld = ldo8 bytes) = sat_fp8(y * scale8)
 hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, bf16_t* out_bf16, int ldo16, float* out_f32,
-                            int ldo32, hipStream_t s, unsigned char* out_fp8 = nullptr, int ldo8 = 0, float scale8 = 1.0f, int f16 = 0);
+                            int ldo32, hipStream_t s, unsigned char* out_fp8 = nullptr, int ldo8 = 0, float scale8 = 1.0f, int f16 = 0,
+                            int lo_off16 = 0);   // lo_off16 != 0: out_bf16[+lo_off16] = rn16(y - rn16(y)) as well
 // fp8 support: tensor amax (atomicMax into *out, which the caller zeroes), per-row weight quantisation, vector scale
 hipError_t launch_amax_bf16(const bf16_t* in, int ld, int rows, int cols, float* out, hipStream_t s);
 hipError_t launch_quantize_weight_fp8(const bf16_t* w, int ld, int rows, int cols, unsigned char* w8, int ld8, float* rowscale,
@@ -137,6 +143,13 @@ hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, flo
 hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, int rows, int dim, hipStream_t s);
 // f32 [rows, cols] -> bf16 [rows, ldo] (columns >= cols zero)
 hipError_t launch_f32_to_bf16(const float* in, int ldi, bf16_t* out, int ldo, int rows, int cols, hipStream_t s, int f16 = 0);
+// hi/lo pairs of 16-bit values from an f32 matrix [rows, cols] (optionally times gamma[k]: the LayerNorm-folded weight from the f32
+// original, one rounding): out rows are [hi | hi | lo] (both = 1: the other operand is split too) or [hi | lo] (both = 0), each part
+// kpad columns (zero padded).  s_out / c_out (optional): s[n] = sum_k (hi + lo), c[n] = sum_k beta[k] w[n][k] + bias[n].
+hipError_t launch_split_weight(const float* w, int ldw, int rows, int cols, const float* gamma, const float* beta, const float* bias,
+                               bf16_t* out, int ld_out, int kpad, int both, float* s_out, float* c_out, hipStream_t s, int f16);
+// hi/lo pair of a f32 [rows, cols] activation: out row = [hi | lo], each part ldhalf columns (zero padded)
+hipError_t launch_f32_to_split16(const float* in, int ldi, bf16_t* out, int ldhalf, int rows, int cols, hipStream_t s, int f16);
 // bf16 [rows, ldi] -> f32 [rows, cols]
 hipError_t launch_bf16_to_f32(const bf16_t* in, int ldi, float* out, int rows, int cols, hipStream_t s, int f16 = 0);
 

@@ -242,6 +242,13 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
             for (int d = 0; d < L::NDB; ++d) {
                 u32x2 pk2 = {OP::pack2(o[d][0] * inv, o[d][1] * inv), OP::pack2(o[d][2] * inv, o[d][3] * inv)};
                 *reinterpret_cast<u32x2*>(orow + d * 16) = pk2;
+                if (p.lo_off) {   // low parts for the split-operand out-projection (wave-uniform)
+                    float lo[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lo[r] = o[d][r] * inv - OP::to_f32(OP::from_f32(o[d][r] * inv));
+                    u32x2 pl = {OP::pack2(lo[0], lo[1]), OP::pack2(lo[2], lo[3])};
+                    *reinterpret_cast<u32x2*>(orow + p.lo_off + d * 16) = pl;
+                }
             }
         }
     }

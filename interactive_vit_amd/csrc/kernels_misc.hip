@@ -106,8 +106,9 @@ hipError_t launch_preprocess(const float* in, int H, int W, float* out, int batc
 // One thread produces 8 consecutive k of one patch row n: 16 B of bf16.  For p % 8 == 0 the 8
 // sources are 8 consecutive pixels of one image row (two float4 loads); otherwise each element is
 // located through unfold_offset().  Columns k >= 3p^2 (K padding up to a multiple of 64) are zero.
+// split (f16 split-operand patch GEMM): an output row is [hi | lo], 2 * kpad columns, hi = rn16(x), lo = rn16(x - hi).
 __global__ void ivit_unfold(const float* __restrict__ in, bf16_t* __restrict__ out, int batch, int image,
-                            int patch, int kpad, int normalise, int f16) {
+                            int patch, int kpad, int normalise, int f16, int split) {
     const int g = image / patch;
     const int np = g * g;
     const int kreal = 3 * patch * patch;
@@ -147,15 +148,24 @@ __global__ void ivit_unfold(const float* __restrict__ in, bf16_t* __restrict__ o
             }
         }
         u32x4 pk = {pack16x2(f16, v[0], v[1]), pack16x2(f16, v[2], v[3]), pack16x2(f16, v[4], v[5]), pack16x2(f16, v[6], v[7])};
-        *reinterpret_cast<u32x4*>(out + row * kpad + k0) = pk;
+        if (!split) {
+            *reinterpret_cast<u32x4*>(out + row * kpad + k0) = pk;
+        } else {
+            float l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) l[e] = v[e] - dec16(f16, enc16(f16, v[e]));
+            u32x4 pl = {pack16x2(f16, l[0], l[1]), pack16x2(f16, l[2], l[3]), pack16x2(f16, l[4], l[5]), pack16x2(f16, l[6], l[7])};
+            *reinterpret_cast<u32x4*>(out + row * 2 * kpad + k0) = pk;
+            *reinterpret_cast<u32x4*>(out + row * 2 * kpad + kpad + k0) = pl;
+        }
     }
 }
 
 hipError_t launch_unfold(const float* in, bf16_t* out, int batch, int image, int patch, int kpad, int normalise,
-                         hipStream_t s, int f16) {
+                         hipStream_t s, int f16, int split) {
     const int g = image / patch;
     const int64_t total = (int64_t)batch * g * g * (kpad / 8);
-    hipLaunchKernelGGL(ivit_unfold, dim3(ew_grid(total)), dim3(EW_THREADS), 0, s, in, out, batch, image, patch, kpad, normalise, f16);
+    hipLaunchKernelGGL(ivit_unfold, dim3(ew_grid(total)), dim3(EW_THREADS), 0, s, in, out, batch, image, patch, kpad, normalise, f16, split);
     return hipGetLastError();
 }
 
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
                                                       int dim, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
                                                       bf16_t* __restrict__ o16, int ldo16, float* __restrict__ o32,
-                                                      int ldo32, unsigned char* __restrict__ o8, int ldo8, float scale8, int f16) {
+                                                      int ldo32, unsigned char* __restrict__ o8, int ldo8, float scale8, int f16, int lo_off16) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
     if (row0 >= rows) return;
@@ -254,6 +264,11 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
                 if (o16) {
                     u32x2 pk = {pack16x2(f16, y.x, y.y), pack16x2(f16, y.z, y.w)};
                     reinterpret_cast<u32x2*>(o16 + (size_t)row * ldo16)[c] = pk;
+                    if (lo_off16) {   // low parts for a split-operand GEMM
+                        u32x2 pl = {pack16x2(f16, y.x - dec16(f16, enc16(f16, y.x)), y.y - dec16(f16, enc16(f16, y.y))),
+                                    pack16x2(f16, y.z - dec16(f16, enc16(f16, y.z)), y.w - dec16(f16, enc16(f16, y.w)))};
+                        reinterpret_cast<u32x2*>(o16 + (size_t)row * ldo16 + lo_off16)[c] = pl;
+                    }
                 }
                 if (o8)   // e4m3 with the tensor's calibrated scale (scale8 = 1 / scale)
                     reinterpret_cast<unsigned int*>(o8 + (size_t)row * ldo8)[c] = pack_fp8x4(y.x * scale8, y.y * scale8, y.z * scale8, y.w * scale8);
@@ -264,12 +279,12 @@ __global__ __launch_bounds__(256) void ivit_layernorm(const float* __restrict__ 
 
 hipError_t launch_layernorm(const float* x, int ldx, int64_t row_stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, bf16_t* o16, int ldo16, float* o32, int ldo32,
-                            hipStream_t s, unsigned char* o8, int ldo8, float scale8, int f16) {
-    if (dim % 4 || dim > 64 * 4 * 8) return hipErrorInvalidValue;
+                            hipStream_t s, unsigned char* o8, int ldo8, float scale8, int f16, int lo_off16) {
+    if (dim % 4 || dim > 64 * 4 * 8 || (lo_off16 % 4)) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
     const dim3 grid(ceil_div(rows, 4 * LN_RPW)), block(256);
     const int vpl = ceil_div(dim / 4, 64);
-#define IVIT_LN(V) hipLaunchKernelGGL(ivit_layernorm<V>, grid, block, 0, s, x, ldx, row_stride, rows, dim, gamma, beta, eps, o16, ldo16, o32, ldo32, o8, ldo8, scale8, f16)
+#define IVIT_LN(V) hipLaunchKernelGGL(ivit_layernorm<V>, grid, block, 0, s, x, ldx, row_stride, rows, dim, gamma, beta, eps, o16, ldo16, o32, ldo32, o8, ldo8, scale8, f16, lo_off16)
     if (vpl <= 1) IVIT_LN(1);
     else if (vpl <= 2) IVIT_LN(2);
     else if (vpl <= 3) IVIT_LN(3);
@@ -439,6 +454,61 @@ __global__ void ivit_f32_to_bf16(const float* __restrict__ in, int ldi, bf16_t* 
 hipError_t launch_f32_to_bf16(const float* in, int ldi, bf16_t* out, int ldo, int rows, int cols, hipStream_t s, int f16) {
     if (ldo % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ivit_f32_to_bf16, dim3(ew_grid((int64_t)rows * ldo / 4)), dim3(EW_THREADS), 0, s, in, ldi, out, ldo, rows, cols, f16);
+    return hipGetLastError();
+}
+
+// [hi | lo] pair of an f32 activation matrix (split-operand head GEMM on a caller's f32 class-token features)
+__global__ void ivit_f32_to_split16(const float* __restrict__ in, int ldi, bf16_t* __restrict__ out, int ldhalf, int rows, int cols, int f16) {
+    const int64_t total = (int64_t)rows * ldhalf;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ldhalf);
+        const int64_t r = i / ldhalf;
+        const float v = c < cols ? in[r * ldi + c] : 0.f;
+        const bf16_t h = enc16(f16, v);
+        out[r * 2 * ldhalf + c] = h;
+        out[r * 2 * ldhalf + ldhalf + c] = enc16(f16, v - dec16(f16, h));
+    }
+}
+hipError_t launch_f32_to_split16(const float* in, int ldi, bf16_t* out, int ldhalf, int rows, int cols, hipStream_t s, int f16) {
+    hipLaunchKernelGGL(ivit_f32_to_split16, dim3(ew_grid((int64_t)rows * ldhalf)), dim3(EW_THREADS), 0, s, in, ldi, out, ldhalf, rows, cols, f16);
+    return hipGetLastError();
+}
+
+// hi/lo pairs of a weight matrix from its f32 original (launch_split_weight, kernels.h).  One wave per weight row.
+__global__ __launch_bounds__(256) void ivit_split_weight(const float* __restrict__ w, int ldw, int rows, int cols, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                         int ld_out, int kpad, int both, float* __restrict__ s_out, float* __restrict__ c_out, int f16) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* wr = w + (size_t)row * ldw;
+    bf16_t* o = out + (size_t)row * ld_out;
+    float s = 0.f, c = 0.f;
+    for (int k = lane; k < kpad; k += 64) {
+        bf16_t h = 0, l = 0;
+        if (k < cols) {
+            const float wv = wr[k];
+            const float v = gamma ? wv * gamma[k] : wv;
+            h = enc16(f16, v);
+            l = enc16(f16, v - dec16(f16, h));
+            s += dec16(f16, h) + dec16(f16, l);
+            if (beta) c = fmaf(beta[k], wv, c);
+        }
+        o[k] = h;
+        if (both) { o[kpad + k] = h; o[2 * kpad + k] = l; }
+        else o[kpad + k] = l;
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if (lane == 0) {
+        if (s_out) s_out[row] = s;
+        if (c_out) c_out[row] = c + (bias ? bias[row] : 0.f);
+    }
+}
+hipError_t launch_split_weight(const float* w, int ldw, int rows, int cols, const float* gamma, const float* beta, const float* bias,
+                               bf16_t* out, int ld_out, int kpad, int both, float* s_out, float* c_out, hipStream_t s, int f16) {
+    if (ld_out < (both ? 3 : 2) * kpad) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivit_split_weight, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w, ldw, rows, cols, gamma, beta, bias, out, ld_out, kpad, both, s_out, c_out, f16);
     return hipGetLastError();
 }
 

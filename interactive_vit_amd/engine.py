@@ -38,8 +38,8 @@ class IvitConfigC(ctypes.Structure):
                 ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
-ABI_VERSION = 6
-PRECISIONS = {"bf16": 0, "fp8": 1, "f16": 2}
+ABI_VERSION = 7
+PRECISIONS = {"bf16": 0, "fp8": 1, "f16": 2, "f16x": 3}
 
 
 _lib = None
@@ -437,7 +437,17 @@ class Engine:
     @property
     def operand_dtype(self) -> torch.dtype:
         """The 16-bit type of the GEMM operand data path (what the oracle's rounding-aware mode has to mirror)."""
-        return torch.float16 if self.precision == "f16" else torch.bfloat16
+        return torch.float16 if self.precision in ("f16", "f16x") else torch.bfloat16
+
+    @property
+    def split_gemms(self) -> frozenset:
+        """The GEMMs this engine multiplies as hi + lo pairs of f16 values (include/ivit.h: IVIT_PRECISION_F16 / F16X) - what the
+        oracle's rounding-aware mode mirrors (oracle/vit_oracle.py: SPLIT_GEMMS)."""
+        if self.precision == "f16x":
+            return frozenset({"patch", "head", "proj", "mlp1w", "mlp2w"})
+        if self.precision == "f16" and os.environ.get("IVIT_F16_SPLIT_PATCH_HEAD", "1") != "0":
+            return frozenset({"patch", "head"})
+        return frozenset()
 
     TAPS = {"h1": 1, "qkv": 2, "att": 3, "proj": 4, "h2": 5, "u": 6, "out": 7}
 
@@ -448,7 +458,7 @@ class Engine:
         batch, _ = self._split_batch(x, 3)
         xin = x.detach().to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
         m = batch * self.cfg.tokens
-        cap = m * max(3 * self.cfg.dim * 2, self.cfg.mlp * 2, self.cfg.dim * 4)
+        cap = m * max(3 * self.cfg.dim * 2, self.cfg.mlp * 2, self.cfg.dim * 4)   # (an F16X attention tap is [hi | lo]: 2 * dim * 2 bytes per row)
         raw = torch.empty(cap, dtype=torch.uint8, device=xin.device)
         rb, eb = ctypes.c_int64(0), ctypes.c_int(0)
         stream = torch.cuda.current_stream(xin.device).cuda_stream

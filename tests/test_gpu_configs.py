@@ -81,9 +81,12 @@ def per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales4=None):
     x0 = tok_gpu[sel].double().cpu().reshape(-1, d)
     batch = tok_gpu.shape[0]
     fold = (not fp8) and eng.ln_fold_for(batch)
+    split = eng.split_gemms        # f16x: GEMMs on hi + lo pairs of f16 values (include/ivit.h: IVIT_PRECISION_F16X)
     tap = {k: eng.layer_tap(layer, tok_gpu, k)[rows.to(tok_gpu.device)].cpu() for k in ("h1", "qkv", "att", "proj", "h2", "u", "out")}
 
-    def wmat(key):
+    def wmat(key, wsplit=False):
+        if wsplit:                                   # hi + lo of the f32 weight
+            return vo.split16(sd[pre + key].to(torch.float32)).to(f64)
         return sd[pre + key].to(torch.float32).to(op).to(f64)
 
     def vec(key):
@@ -100,9 +103,13 @@ def per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales4=None):
         mu = x.mean(dim=-1, keepdim=True)
         return mu, 1.0 / torch.sqrt(((x - mu) ** 2).mean(dim=-1, keepdim=True) + cfg.ln_eps)
 
-    def folded(x, xb, wkey, bkey, gkey, btkey):
-        wb = wmat(wkey)
-        wf = (wb * vec(gkey)[None, :]).to(torch.float32).to(op).to(f64)
+    def folded(x, xb, wkey, bkey, gkey, btkey, wsplit=False):
+        if wsplit:                                   # W' = hi + lo of the f32 product W . gamma; c from the f32 matrix
+            wb = sd[pre + wkey].to(f64)
+            wf = vo.split16(sd[pre + wkey].to(torch.float32) * sd[pre + gkey].to(torch.float32)[None, :]).to(f64)
+        else:
+            wb = wmat(wkey)
+            wf = (wb * vec(gkey)[None, :]).to(torch.float32).to(op).to(f64)
         mu, rstd = stats(x)
         return rstd * (xb @ wf.t() - mu * wf.sum(dim=1)) + (wb @ vec(btkey) + vec(bkey))
 
@@ -138,7 +145,14 @@ def per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales4=None):
     qkv = tap["qkv"].to(f64).reshape(len(sel), n, 3 * d)
     a, _ = vo.attention_core(qkv, cfg, emulate=True, p_dtype=torch.bfloat16 if fp8 else op)
     a = a.reshape(-1, d)
-    if fp8:
+    att_in = tap["att"]
+    if "proj" in split:                              # the attention output is stored as [hi | lo]
+        assert att_in.shape[1] == 2 * d
+        att_hi, att_lo = att_in[:, :d], att_in[:, d:]
+        check_stored("att (hi)", att_hi, a.to(torch.float32).to(op), mb16, tiny16, floor=5e-2)
+        assert bool((att_lo.double().abs() <= att_hi.double().abs() * 2.0 ** -11 + 2.0 ** -24).all()), "lo must be the rounding residual of hi"
+        att_in = att_hi.to(f64) + att_lo.to(f64)
+    elif fp8:
         check_stored("att (-> e4m3)", tap["att"].to(torch.float32), quant(a, s_att).to(torch.float32), *storage(torch.float8_e4m3fn), floor=5e-2)
     else:
         check_stored("att", tap["att"], a.to(torch.float32).to(op), mb16, tiny16, floor=5e-2)
@@ -147,7 +161,7 @@ def per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales4=None):
         w8, rs = q8(1)
         ref = x0 + (tap["att"].to(torch.float32).to(f64) @ w8.t()) * (s_att * rs).double()[None, :] + vec("self_attention.out_proj.bias")
     else:
-        ref = x0 + tap["att"].to(f64) @ wmat("self_attention.out_proj.weight").t() + vec("self_attention.out_proj.bias")
+        ref = x0 + att_in.to(f64) @ wmat("self_attention.out_proj.weight", "proj" in split).t() + vec("self_attention.out_proj.bias")
     e = rel_err(tap["proj"], ref)
     print(f"   proj (+ residual, f32): {e:.2e}")
     assert e <= F32_TOL
@@ -166,17 +180,17 @@ def per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales4=None):
         pre_act = (h2.to(torch.float32).to(f64) @ w8.t()) * (s_h2 * rs).double()[None, :] + vec("mlp.0.bias")
         check_stored("u (fp8 GEMM + GELU -> e4m3)", tap["u"].to(torch.float32), quant(vo.gelu_erf(pre_act), s_u).to(torch.float32), *storage(torch.float8_e4m3fn), floor=1e-2)
     elif fold:
-        pre_act = folded(x1, h2.to(f64), "mlp.0.weight", "mlp.0.bias", "ln_2.weight", "ln_2.bias")
+        pre_act = folded(x1, h2.to(f64), "mlp.0.weight", "mlp.0.bias", "ln_2.weight", "ln_2.bias", "mlp1w" in split)
         check_stored("u (LN-fold GEMM + GELU)", tap["u"], vo.gelu_erf(pre_act).to(torch.float32).to(op), mb16, tiny16)
     else:
-        pre_act = h2.to(f64) @ wmat("mlp.0.weight").t() + vec("mlp.0.bias")
+        pre_act = h2.to(f64) @ wmat("mlp.0.weight", "mlp1w" in split).t() + vec("mlp.0.bias")
         check_stored("u (GEMM + GELU)", tap["u"], vo.gelu_erf(pre_act).to(torch.float32).to(op), mb16, tiny16)
     # ---- step 7: MLP down + residual
     if fp8:
         w8, rs = q8(3)
         ref = x1 + (tap["u"].to(torch.float32).to(f64) @ w8.t()) * (s_u * rs).double()[None, :] + vec("mlp.3.bias")
     else:
-        ref = x1 + tap["u"].to(f64) @ wmat("mlp.3.weight").t() + vec("mlp.3.bias")
+        ref = x1 + tap["u"].to(f64) @ wmat("mlp.3.weight", "mlp2w" in split).t() + vec("mlp.3.bias")
     e = rel_err(tap["out"], ref)
     print(f"   out (MLP down + residual, f32): {e:.2e}")
     assert e <= F32_TOL
@@ -190,6 +204,7 @@ def run_config(model, batch, precision, expect_gemm, expect_fold, layers_to_chec
     eng = Engine(cfg, sd, device=0, max_batch=batch, precision=precision)
     try:
         vo.OPERAND_DTYPE = eng.operand_dtype
+        vo.SPLIT_GEMMS = eng.split_gemms
         x = synthetic_images(batch, cfg, seed=5)
         scales = eng.calibrate_fp8(x[:4]) if precision == "fp8" else None
         tok = oracle_tokens(cfg, sd, x)                         # [B,N,D] f32 on the host: cheap, no encoder layer
@@ -223,6 +238,7 @@ def run_config(model, batch, precision, expect_gemm, expect_fold, layers_to_chec
             per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales[4 * layer:4 * layer + 4] if scales else None)
     finally:
         vo.OPERAND_DTYPE = torch.bfloat16
+        vo.SPLIT_GEMMS = frozenset()
         eng.close()
 
 
@@ -385,3 +401,11 @@ def test_config2_vit_b16_batch64_f16_as_dispatched():
                 "mlp1": "ivit_gemm_f16_160x128x64_sb_lf", "mlp2": "ivit_gemm_f16_160x128x64"},
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
+
+def test_config2_vit_b16_batch64_f16x_as_dispatched():
+    """IVIT_PRECISION_F16X at the bench batch: the out-projection on hi + lo pairs of both operands, MLP up / down on hi + lo weight
+    pairs - every step gated on the engine's own operand bytes (the attention tap carries [hi | lo])."""
+    run_config("vit_b_16", 64, "f16x",
+               {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs",
+                "mlp1": "ivit_gemm_f16_160x128x64_sb_lf", "mlp2": "ivit_gemm_f16_160x128x64"},
+               expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)

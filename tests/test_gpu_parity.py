@@ -638,15 +638,17 @@ def test_fp8_vit_h14():
 F16_VS_F32_NODE = 1e-3
 
 
-def test_f16_every_node_within_1e3_of_the_plain_f32_forward():
+@pytest.mark.parametrize("precision", ["f16", "f16x"])
+def test_f16_every_node_within_1e3_of_the_plain_f32_forward(precision):
     from interactive_vit_amd.engine import Engine
     from oracle import vit_oracle
     cfg = small_config()
     sd = init_weights(cfg, seed=3, mode="rich")
-    eng = Engine(cfg, sd, device=0, max_batch=3, precision="f16")
+    eng = Engine(cfg, sd, device=0, max_batch=3, precision=precision)
     try:
         assert eng.operand_dtype == torch.float16
         vit_oracle.OPERAND_DTYPE = torch.float16
+        vit_oracle.SPLIT_GEMMS = eng.split_gemms
         vit_oracle.LN_FOLD = eng.ln_fold
         x = synthetic_images(3, cfg, seed=5)
         acts = vit_oracle.forward(x, sd, cfg, keep=True)
@@ -666,27 +668,32 @@ def test_f16_every_node_within_1e3_of_the_plain_f32_forward():
         assert torch.equal(logits, eng.forward(x.cuda(), 0, len(eng.stages)).cpu())
     finally:
         vit_oracle.OPERAND_DTYPE = torch.bfloat16
+        vit_oracle.SPLIT_GEMMS = frozenset()
         eng.close()
 
 
-def test_f16_vit_b16_batch64_nodes_and_chain():
-    """BASELINE config 2's shapes in f16: the 256x256 / 160x128 f16 tiles with the LayerNorm fold, 197-key attention;
-    per node 1e-3 vs the plain f32 oracle; the 12-layer chain is reported (it accumulates 50 rounded GEMMs)."""
+@pytest.mark.parametrize("precision,chain_tol", [("f16", 1.3e-3), ("f16x", 1e-3)])
+def test_f16_vit_b16_batch64_nodes_and_chain(precision, chain_tol):
+    """BASELINE config 2's shapes on the f16 data paths: per node 1e-3 vs the plain f32 oracle; the whole 12-layer chain (50 GEMMs)
+    against the plain f32 forward: IVIT_PRECISION_F16X (split-operand out-projection and MLP weights) is gated at north_star's 1e-3
+    (7e-4 by the oracle's emulation, tools/f16_error_terms.py); IVIT_PRECISION_F16 at its measured 1.0e-3 + 25 %."""
     from interactive_vit_amd.engine import Engine
     from oracle import vit_oracle
     cfg = VARIANTS["vit_b_16"]
     sd = init_weights(cfg, seed=0, mode="spec")
-    eng = Engine(cfg, sd, device=0, max_batch=64, precision="f16")
+    eng = Engine(cfg, sd, device=0, max_batch=64, precision=precision)
     try:
         vit_oracle.OPERAND_DTYPE = torch.float16
+        vit_oracle.SPLIT_GEMMS = eng.split_gemms
         x = synthetic_images(64, cfg, seed=1234)
         xg = x.cuda()
         logits = eng.forward(xg, 0, len(eng.stages))
         assert torch.equal(logits, eng.forward(xg, 0, len(eng.stages)))
         acts = vit_oracle.forward(x[:2], sd, cfg, keep=True)
         e = rel_err(logits[:2], acts["logits"])
-        print(f"f16 vit_b_16 logits (whole chain, B = 64) vs plain f32 {e:.2e}")
-        assert e <= 2e-3                                   # bf16: 9.3e-3
+        e4 = rel_err(logits[:4], vit_oracle.forward(x[:4], sd, cfg)["logits"])
+        print(f"{precision} vit_b_16 logits (whole chain, B = 64) vs plain f32: {e:.2e} (2 images), {e4:.2e} (4 images)")
+        assert max(e, e4) <= chain_tol                     # bf16: 9.3e-3
         order = vit_oracle.node_suffixes(cfg)
         # full batch through single nodes (the tiles the benchmark batch dispatches), two images checked
         tok = vit_oracle.tokens(vit_oracle.conv_proj(vit_oracle.transform(x), sd, cfg), sd, cfg)
@@ -710,6 +717,7 @@ def test_f16_vit_b16_batch64_nodes_and_chain():
         assert torch.equal(alone[0], logits[17]), "image 17 depends on its batch"
     finally:
         vit_oracle.OPERAND_DTYPE = torch.bfloat16
+        vit_oracle.SPLIT_GEMMS = frozenset()
         eng.close()
 
 
