@@ -227,6 +227,7 @@ struct ivit_engine {
     bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
     bool fold_blocked = false;      // ivit_ln_fold_calibrate found rows with |mean| / std above its threshold: keep the LayerNorm kernels
     float* ratio_dev = nullptr;     // calibration scratch: max |mean| / std seen (non-null only while calibrating)
+    float* ratio_scratch = nullptr; // its device word, allocated once at ivit_create
     bool ratio_on = false;
     float2* ln_part = nullptr;
     int graph_max_batch = 4;
@@ -430,6 +431,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         for (auto& lw : e->layers) { alloc8(&lw.q_in, 3 * D, D); alloc8(&lw.q_out, D, D); alloc8(&lw.q1, Mlp, D); alloc8(&lw.q2, D, Mlp); }
     }
     chk(alloc_vec(e, &e->clsf, (int64_t)B * D));
+    chk(alloc_vec(e, &e->ratio_scratch, 4));
     int64_t per_img = 0;
     for (int s = 0; s < 6 + cfg->layers; ++s)
         for (int w = 0; w < 2; ++w) per_img = std::max(per_img, shape_elems(cfg, s, w));
@@ -876,6 +878,20 @@ static int ws_release(ivit_engine* e, hipStream_t st) {
     e->ws_used = true;
     return 0;
 }
+// The hand-over must be recorded on EVERY exit of a call that took the workspaces - also when a launch inside it failed and the
+// function returns early: otherwise the next call, on another stream, is not ordered behind the partial work already queued.
+struct WsScope {
+    ivit_engine* e; hipStream_t st; bool held = false;
+    WsScope(ivit_engine* e_, hipStream_t st_) : e(e_), st(st_) {}
+    int acquire() { if (ws_acquire(e, st)) return 1; held = true; return 0; }
+    int release() { held = false; return ws_release(e, st); }
+    ~WsScope() {
+        if (!held) return;
+        const std::string keep = t_last_error;                  // the message of the failure that brought us here
+        if (hipEventRecord(e->ev_ws, st) == hipSuccess) e->ws_used = true;
+        t_last_error = keep;
+    }
+};
 
 static Ws ws_slice(ivit_engine* e, int b0) {
     const size_t rt = (size_t)b0 * e->N, rp = (size_t)b0 * e->Np;
@@ -927,9 +943,10 @@ extern "C" int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_en
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
-    if (ws_acquire(e, st)) return 1;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
     const int rc = forward_locked(e, stage_begin, stage_end, batch, (const float*)in, (float*)out, (float*)cls_out, st);
-    if (ws_release(e, st)) return 1;
+    if (ws.release()) return 1;
     return rc;
 }
 
@@ -969,7 +986,8 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
     // (nothing has touched them since: ws_acquire clears the token), and that output is this call's input: skip ivit_row_stats_pairs
     const bool chained_stats = in_token != 0 && in_token == e->resident_token && n_in == e->resident_elems &&
                                e->stats_token == in_token && e->stats_batch == batch && begins_on_layer && folds;
-    if (ws_acquire(e, st)) return 1;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
     if (in_token != 0 && in_token == e->resident_token && n_in == e->resident_elems) {
         std::swap(e->ext_in, e->ext_out);   // the previous call's output is this call's input: no upload
     } else {
@@ -1018,7 +1036,7 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
         if (forward_locked(e, stage_begin, stage_end, batch, e->ext_in, e->ext_out, nullptr, st, chained_stats, leave_stats)) return 1;
     }
     if (!done && copy_out_async(e, out, e->ext_out, n_out, st)) return 1;
-    if (ws_release(e, st)) return 1;
+    if (ws.release()) return 1;
     if (ticket) {   // asynchronous form: the caller waits for this call's D2H copy through ivit_host_wait(ticket)
         const uint64_t tk = ++e->done_counter;
         HIP_TRY(hipEventRecord(e->ev_done[tk % ivit_engine::DONE_RING], e->copy_stream));
@@ -1091,9 +1109,10 @@ extern "C" int ivit_attention_map(ivit_engine* e, int layer, int batch, const vo
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
-    if (ws_acquire(e, st)) return 1;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
     const int rc = attention_map_locked(e, layer, batch, (const float*)in, (float*)out, st);
-    if (ws_release(e, st)) return 1;
+    if (ws.release()) return 1;
     return rc;
 }
 
@@ -1113,12 +1132,13 @@ extern "C" int ivit_attention_map_host(ivit_engine* e, int layer, int batch, con
         HIP_TRY(hipMalloc((void**)&e->map_buf, need));
         e->map_bytes = need;
     }
-    if (ws_acquire(e, st)) return 1;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
     if (ext_buffer_writable(e, e->ext_in, st)) return 1;
     HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_in * 4, hipMemcpyHostToDevice, st));
     if (attention_map_locked(e, layer, batch, e->ext_in, e->map_buf, st)) return 1;
     HIP_TRY(hipMemcpyAsync(out, e->map_buf, need, hipMemcpyDeviceToHost, st));
-    if (ws_release(e, st)) return 1;
+    if (ws.release()) return 1;
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
@@ -1155,13 +1175,14 @@ extern "C" int ivit_preprocess_host(ivit_engine* e, int batch, const float* in, 
         HIP_TRY(hipMalloc((void**)&e->pre_buf, need));
         e->pre_bytes = need;
     }
-    if (ws_acquire(e, st)) return 1;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
     e->resident_token = 0;
     if (ext_buffer_writable(e, e->ext_out, st)) return 1;
     HIP_TRY(hipMemcpyAsync(e->pre_buf, in, need, hipMemcpyHostToDevice, st));
     HIP_TRY(launch_preprocess(e->pre_buf, height, width, e->ext_out, batch, S, preprocess_resize(e), st));
     HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
-    if (ws_release(e, st)) return 1;
+    if (ws.release()) return 1;
     HIP_TRY(hipStreamSynchronize(st));
     // the result stays resident like any host-path output: `conv_proj` can take it without an upload
     e->resident_token = ++e->token_counter;
@@ -1179,7 +1200,8 @@ extern "C" int ivit_fp8_calibrate(ivit_engine* e, int batch, const void* in, voi
     if (require_weights(e)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int L = e->cfg.layers, D = e->D, Mlp = e->cfg.mlp;
-    if (ws_acquire(e, st)) return 1;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
     // 1. one bf16 forward of the calibration batch, recording max|.| of every fp8-bound tensor
     HIP_TRY(hipMemsetAsync(e->amax_dev, 0, (size_t)(L * 4 + 4) * sizeof(float), st));
     const Ws w = ws_slice(e, 0);
@@ -1202,7 +1224,7 @@ extern "C" int ivit_fp8_calibrate(ivit_engine* e, int batch, const void* in, voi
         }
     }
     (void)D; (void)Mlp;
-    if (ws_release(e, st)) return 1;
+    if (ws.release()) return 1;
     HIP_TRY(hipStreamSynchronize(st));
     e->fp8_ready = true;
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);   // captured launches embed the old scales
@@ -1218,9 +1240,9 @@ extern "C" int ivit_ln_fold_calibrate(ivit_engine* e, int batch, const void* in,
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (require_weights(e)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    if (ws_acquire(e, st)) return 1;
-    float* dev = nullptr;
-    HIP_TRY(hipMalloc((void**)&dev, sizeof(float)));
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
+    float* dev = e->ratio_scratch;
     int rc = 0;
     float ratio = 0.f;
     do {
@@ -1234,10 +1256,9 @@ extern "C" int ivit_ln_fold_calibrate(ivit_engine* e, int batch, const void* in,
         if (hipMemcpyAsync(&ratio, dev, sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = fail("reading the calibration statistic failed"); break; }
     } while (0);
     e->ratio_on = false; e->ratio_dev = nullptr;
-    (void)hipFree(dev);
-    if (ws_release(e, st)) return 1;
+    if (ws.release()) return 1;
     if (rc) return 1;
-    const bool blocked = ratio > threshold;
+    const bool blocked = !(ratio <= threshold);   // a non-finite statistic (NaN wins the unsigned atomicMax of the kernel) blocks the fold too
     if (blocked != e->fold_blocked) {   // captured launch sequences embed the old choice
         for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
         e->graphs.clear();
@@ -1266,10 +1287,11 @@ extern "C" int ivit_debug_unfold(ivit_engine* e, int batch, const void* in, void
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
-    if (ws_acquire(e, st)) return 1;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
     HIP_TRY(launch_unfold((const float*)in, e->patches, batch, e->cfg.image, e->cfg.patch, e->Kp, normalise ? 1 : 0, st, e->f16));
     HIP_TRY(launch_bf16_to_f32(e->patches, e->Kp, (float*)out, batch * e->Np, e->K, st, e->f16));
-    return ws_release(e, st);
+    return ws.release();
 }
 
 extern "C" int ivit_debug_layer_tap(ivit_engine* e, int layer, int batch, const void* in, int tap, void* out, int64_t out_capacity_bytes,
@@ -1294,13 +1316,14 @@ extern "C" int ivit_debug_layer_tap(ivit_engine* e, int layer, int batch, const 
         default: src = w.x; eb = 4; rb = 4 * D; break;   // TAP_PROJ, TAP_OUT: the f32 residual stream
     }
     if ((int64_t)M * rb > out_capacity_bytes) return fail("ivit_debug_layer_tap: output needs %lld bytes, capacity is %lld", (long long)M * rb, (long long)out_capacity_bytes);
-    if (ws_acquire(e, st)) return 1;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
     HIP_TRY(hipMemcpyAsync(w.x, in, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
     if (run_layer(e, w, st, layer, batch, nullptr, false, false, tap)) return 1;
     HIP_TRY(hipMemcpyAsync(out, src, (size_t)M * rb, hipMemcpyDeviceToDevice, st));
     if (row_bytes) *row_bytes = rb;
     if (elem_bytes) *elem_bytes = eb;
-    return ws_release(e, st);
+    return ws.release();
 }
 
 extern "C" int ivit_debug_weight_fp8(ivit_engine* e, int layer, int which, void* out_bytes, int64_t out_capacity_bytes, float* out_rowscale,

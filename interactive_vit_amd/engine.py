@@ -134,6 +134,7 @@ class PendingTensor(torch.Tensor):
             eng = self._ivit_engine()
             if eng is not None and eng._h is not None and eng._h.value:
                 eng._check(eng.lib.ivit_host_wait(eng._h, ctypes.c_uint64(self._ivit_ticket)))
+                eng._retire(self._ivit_ticket)
             self._ivit_done = True
 
     @classmethod
@@ -200,6 +201,8 @@ class Engine:
         # host path: return lazily-synchronised tensors (the D2H copy of a node overlaps the next node's kernels)
         self._async = self._pin and os.environ.get("IVIT_ASYNC_OUTPUTS", "1") != "0"
         self._last_out = None     # (weakref to the last host-path output, its version counter, its residency token)
+        self._held = {}           # ticket -> page-locked result buffer the copy stream may still be writing (see _hold)
+        self._held_lock = threading.Lock()
         self.device = int(device)
         self.max_batch = int(max_batch)
         self.precision = precision
@@ -223,8 +226,11 @@ class Engine:
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
-            self.lib.ivit_destroy(self._h)
+            self.lib.ivit_destroy(self._h)      # synchronises the device: every copy has landed
             self._h = ctypes.c_void_p()
+        if getattr(self, "_held", None):
+            with self._held_lock:
+                self._held.clear()
 
     def __del__(self):
         try:
@@ -265,6 +271,27 @@ class Engine:
         raise EngineError(f"{self.cfg.name}:{self.stages[stage]} expects input {list(want)} "
                           f"(optionally with a leading batch axis), got {list(x.shape)}")
 
+    # -- page-locked result buffers of asynchronous host calls ------------------------------------
+    # The D2H copy that fills such a buffer runs on the engine's own copy stream, which torch's caching host allocator knows nothing
+    # about: a caller that drops its PendingTensor before anything waited on it (a later node raised and the request ended in HTTP 400,
+    # or an output nobody reads) would hand the block back to the pool while the DMA is still writing it.  So the engine holds every
+    # buffer until its ticket has completed: tickets complete in order (one copy stream), a wait on ticket t retires every ticket <= t,
+    # and the number of held buffers is bounded by waiting for the oldest.
+    _MAX_HELD = 32
+
+    def _hold(self, ticket: int, buf: torch.Tensor) -> None:
+        with self._held_lock:
+            self._held[ticket] = buf
+            oldest = min(self._held) if len(self._held) > self._MAX_HELD else None
+        if oldest is not None and self._h is not None and self._h.value:
+            self._check(self.lib.ivit_host_wait(self._h, ctypes.c_uint64(oldest)))
+            self._retire(oldest)
+
+    def _retire(self, ticket: int) -> None:
+        with self._held_lock:
+            for t in [t for t in self._held if t <= ticket]:
+                del self._held[t]
+
     # -- forward -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, begin: int, end: int, want_cls: bool = False):
         """Runs stages [begin, end).  CPU input -> CPU f32 output (host path); CUDA input -> CUDA
@@ -299,6 +326,7 @@ class Engine:
                 res = PendingTensor.wrap(out, self, ticket.value)
                 with torch._C.DisableTorchFunctionSubclass():
                     self._last_out = (weakref.ref(res), res._version, new_token.value)
+                self._hold(ticket.value, out)
                 return res
             self._check(self.lib.ivit_forward_host_chained(self._h, begin, end, batch, ctypes.c_void_p(in_ptr),
                                                            ctypes.c_void_p(out.data_ptr()), out.numel(),

@@ -193,7 +193,17 @@ def instances():
         from ..context import Model as ModelBase
         from ..graph import Pinout as PinoutCls
     variants = tuple(v for v in os.environ.get("IVIT_VARIANTS", "vit_b_16").split(",") if v)
-    return build_plugins(ModelBase, PinoutCls, variants,
+    # IVIT_WEIGHTS = "<path>" (one variant) or "vit_b_16=<path>,vit_l_16_384=<path>": local checkpoints in torchvision key names
+    # (weights.load_state_dict_file); variants without one get the seeded synthetic initialisation.  IVIT_CATEGORIES = label file.
+    state_dicts = {}
+    spec = os.environ.get("IVIT_WEIGHTS", "")
+    if spec:
+        from ..weights import load_state_dict_file
+        for item in spec.split(","):
+            name, _, path = item.rpartition("=")
+            name = name or variants[0]
+            state_dicts[name] = load_state_dict_file(path, VARIANTS[name])
+    return build_plugins(ModelBase, PinoutCls, variants, state_dicts=state_dicts,
                          device=int(os.environ.get("IVIT_DEVICE", "0")),
                          max_batch=int(os.environ.get("IVIT_MAX_BATCH", "1")),
                          precision=os.environ.get("IVIT_PRECISION", "bf16"))

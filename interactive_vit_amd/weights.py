@@ -68,6 +68,43 @@ def init_weights(cfg: VitConfig, seed: int = 0, mode: str = "spec") -> Dict[str,
     return sd
 
 
+def load_state_dict_file(path: str, cfg: VitConfig) -> Dict[str, torch.Tensor]:
+    """A LOCAL checkpoint in torchvision ``VisionTransformer`` key names -> the f32 state dict ``ivit_set_weight`` takes.
+
+    The reference's model plugin loads real weights (static/models/vgg16.py:12-14, a network download); there is no network
+    here, so the file is whatever the operator provides: ``.safetensors`` (read with the safetensors package, no pickle) or a
+    ``torch.save`` state dict (``weights_only=True``).  Tensors may be f32 / bf16 / f16 and non-contiguous; every one is
+    checked against ``weight_shapes(cfg)`` (a conv_proj weight may come flattened [D, 3 p p]; a timm-style ``[1, N, D]`` /
+    ``[N, D]`` position embedding is accepted) and converted to contiguous f32.  Unknown extra keys are ignored (e.g. the
+    ``heads.pre_logits`` of some checkpoints would change the model: those raise)."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        raw = load_file(path, device="cpu")
+    else:
+        raw = torch.load(path, map_location="cpu", weights_only=True)
+        if isinstance(raw, dict) and "state_dict" in raw and isinstance(raw["state_dict"], dict):
+            raw = raw["state_dict"]
+    if not isinstance(raw, dict):
+        raise ValueError(f"{path}: not a state dict")
+    if any(k.startswith("heads.pre_logits") for k in raw):
+        raise ValueError(f"{path}: checkpoint has a pre_logits head, which this ViT definition (SURVEY App. B) does not have")
+    shapes = weight_shapes(cfg)
+    sd: Dict[str, torch.Tensor] = {}
+    for name, shape in shapes.items():
+        if name not in raw:
+            raise KeyError(f"{path}: missing tensor '{name}' for {cfg.name}")
+        t = raw[name]
+        if not torch.is_floating_point(t):
+            raise TypeError(f"{path}: '{name}' has dtype {t.dtype}")
+        t = t.detach().to(torch.float32)
+        if tuple(t.shape) != tuple(shape):
+            if t.numel() != int(torch.tensor(shape).prod()):
+                raise ValueError(f"{path}: '{name}' has shape {tuple(t.shape)}, expected {tuple(shape)}")
+            t = t.reshape(shape)
+        sd[name] = t.contiguous()
+    return sd
+
+
 def state_digest(sd: Dict[str, torch.Tensor]) -> str:
     """sha256 over names and raw float32 bytes, in key order - pins a seeded state dict."""
     h = hashlib.sha256()

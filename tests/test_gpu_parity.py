@@ -773,3 +773,80 @@ def test_async_host_outputs_are_lazy_and_bit_identical(small, monkeypatch):
             other.close()
     finally:
         sync_eng.close()
+
+
+def test_dropped_pending_output_keeps_its_buffer_until_the_copy_has_landed(small):
+    """a PendingTensor dropped before anything waited on it must not hand its page-locked block back to torch's
+    pool while the engine's copy stream is still writing it.  The engine holds the buffer until its ticket has completed."""
+    import gc
+    from interactive_vit_amd.engine import PendingTensor
+    cfg, sd, eng = small
+    assert eng._async
+    img = synthetic_images(1, cfg, seed=91)[0]
+    want = eng.forward(img, 0, 2).clone()                      # (waits) the reference bytes
+    for _ in range(4):
+        out = eng.forward(img, 0, 2)
+        assert isinstance(out, PendingTensor)
+        ptr, nbytes, ticket = out._ivit_ptr, out.numel() * 4, out._ivit_ticket
+        del out
+        gc.collect()
+        assert ticket in eng._held, "the engine must hold the buffer of a ticket nobody waited for"
+        # the same-sized pinned allocation that follows must NOT get the block the DMA may still be writing
+        other = torch.empty(nbytes // 4, dtype=torch.float32, pin_memory=True)
+        assert other.data_ptr() != ptr
+        other.fill_(-7.0)
+        held = eng._held[ticket]
+        eng._check(eng.lib.ivit_host_wait(eng._h, __import__("ctypes").c_uint64(ticket)))
+        eng._retire(ticket)
+        assert ticket not in eng._held
+        assert torch.equal(held.reshape(want.shape), want) and bool((other == -7.0).all())
+    # the number of held buffers stays bounded when nobody ever waits
+    for _ in range(eng._MAX_HELD + 8):
+        eng.forward(img, 0, 1)
+    assert len(eng._held) <= eng._MAX_HELD + 1
+
+
+def test_a_failed_call_still_hands_the_workspaces_over():
+    """a call that fails AFTER it took the shared workspaces (here: a layer tap on an fp8 engine that was
+    never calibrated - run_layer refuses behind ws_acquire) must still record the hand-over event and keep its own message;
+    the next call, on another stream, then runs normally."""
+    from interactive_vit_amd.engine import Engine, EngineError
+    cfg = small_config()
+    sd = init_weights(cfg, seed=3, mode="rich")
+    eng = Engine(cfg, sd, device=0, max_batch=2, precision="fp8")
+    try:
+        x = synthetic_images(2, cfg, seed=5)
+        tok = torch.randn(2, cfg.tokens, cfg.dim, device="cuda")
+        with pytest.raises(EngineError, match="not calibrated"):
+            eng.layer_tap(0, tok, "qkv")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                       # another stream: ordered behind the failed call's partial work by the event
+            eng.calibrate_fp8(x)
+            out = eng.forward(x.cuda(), 0, len(eng.stages))
+        side.synchronize()
+        assert torch.isfinite(out).all()
+    finally:
+        eng.close()
+
+
+def test_checkpoint_file_through_the_engine(tmp_path):
+    """A local safetensors checkpoint with mixed-precision tensors -> weights.load_state_dict_file -> ivit_set_weight: the engine's
+    forward equals the one on the same values handed over as a dict, and the LayerNorm-fold guard runs on it."""
+    from safetensors.torch import save_file
+    from interactive_vit_amd.models.vit import HipBackend
+    from interactive_vit_amd.weights import load_state_dict_file
+    cfg = small_config()
+    sd = init_weights(cfg, seed=21, mode="rich")
+    stored = {k: v.to(torch.bfloat16 if i % 2 else torch.float32) for i, (k, v) in enumerate(sd.items())}
+    path = str(tmp_path / "ckpt.safetensors")
+    save_file(stored, path)
+    loaded = load_state_dict_file(path, cfg)
+    same = {k: v.to(torch.float32) for k, v in stored.items()}
+    a = HipBackend(cfg, loaded, device=0, max_batch=2)
+    b = HipBackend(cfg, same, device=0, max_batch=2)
+    try:
+        assert a.ln_fold_ratio is not None and a.ln_fold_ratio == b.ln_fold_ratio
+        x = synthetic_images(2, cfg, seed=4)
+        assert torch.equal(a.run_node("forward", x), b.run_node("forward", x))
+    finally:
+        a.engine.close(); b.engine.close()

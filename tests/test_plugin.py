@@ -144,6 +144,9 @@ def test_pending_tensor_waits_once_and_only_when_read():
         def _check(self, rc):
             assert rc == 0
 
+        def _retire(self, ticket):                 # the engine drops the buffers of completed tickets (Engine._hold / _retire)
+            self.retired = getattr(self, "retired", []) + [ticket]
+
     eng = Eng()
     base = torch.arange(6, dtype=torch.float32).reshape(2, 3)
     t = PendingTensor.wrap(base, eng, 7)
@@ -161,3 +164,57 @@ def test_pending_tensor_waits_once_and_only_when_read():
     t2 = PendingTensor.wrap(base.clone(), eng, 9)
     t2.mul_(0.5)                                            # an in-place write waits first, then bumps the version
     assert eng.lib.calls == [7, 9]
+
+
+def test_checkpoint_file_in_torchvision_names_loads(tmp_path):
+    """SURVEY section 5 "checkpoint / resume" (the reference plugin loads real weights, static/models/vgg16.py:12-14): a local
+    safetensors file with torchvision key names - bf16 / f16 / f32 tensors, a flattened conv weight, extra keys - becomes the
+    f32 state dict the engine takes; a torch.save file works too; missing tensors and wrong shapes name the offender."""
+    from safetensors.torch import save_file
+    from interactive_vit_amd.weights import load_state_dict_file, weight_shapes
+    cfg = small_config()
+    sd = init_weights(cfg, seed=11, mode="rich")
+    stored = {}
+    for i, (k, v) in enumerate(sd.items()):
+        stored[k] = v.to([torch.float32, torch.bfloat16, torch.float16][i % 3]).contiguous()
+    stored["conv_proj.weight"] = sd["conv_proj.weight"].reshape(cfg.dim, -1).contiguous()     # flattened [D, 3 p p]
+    stored["some.optimizer.state"] = torch.zeros(3)
+    path = str(tmp_path / "vit.safetensors")
+    save_file(stored, path)
+    got = load_state_dict_file(path, cfg)
+    assert list(got) == list(weight_shapes(cfg))
+    for i, (k, v) in enumerate(sd.items()):
+        assert got[k].dtype == torch.float32 and got[k].is_contiguous() and tuple(got[k].shape) == tuple(v.shape)
+        want = v if k == "conv_proj.weight" else v.to([torch.float32, torch.bfloat16, torch.float16][i % 3]).to(torch.float32)
+        assert torch.equal(got[k], want), k
+    # the oracle runs on it (so does the engine: test_gpu_parity.test_checkpoint_file_through_the_engine)
+    from oracle import vit_oracle as vo
+    x = synthetic_images(1, cfg, seed=1)
+    assert torch.isfinite(vo.forward(x, got, cfg)["logits"]).all()
+    # torch.save form
+    p2 = str(tmp_path / "vit.pt")
+    torch.save({"state_dict": sd}, p2)
+    got2 = load_state_dict_file(p2, cfg)
+    assert all(torch.equal(got2[k], sd[k]) for k in sd)
+    # errors name the tensor
+    broken = dict(stored); del broken["heads.head.bias"]
+    save_file(broken, path)
+    with pytest.raises(KeyError, match="heads.head.bias"):
+        load_state_dict_file(path, cfg)
+    broken = dict(stored); broken["encoder.ln.weight"] = torch.zeros(cfg.dim + 1)
+    save_file(broken, path)
+    with pytest.raises(ValueError, match="encoder.ln.weight"):
+        load_state_dict_file(path, cfg)
+
+
+def test_category_labels_come_from_a_local_file(tmp_path, monkeypatch):
+    """The graph JSON closes with a `category` node carrying the class names (static/models/vgg16.py:16-29); without network the labels
+    come from a local file (IVIT_CATEGORIES), one per line."""
+    from interactive_vit_amd.models.vit import default_categories
+    cfg = small_config()
+    f = tmp_path / "labels.txt"
+    f.write_text("\n".join(f"label {i}" for i in range(cfg.classes)) + "\n")
+    monkeypatch.setenv("IVIT_CATEGORIES", str(f))
+    assert default_categories(cfg.classes) == [f"label {i}" for i in range(cfg.classes)]
+    f.write_text("too\nfew\n")
+    assert default_categories(cfg.classes)[0] == "class 0"          # a file of the wrong length is not used
