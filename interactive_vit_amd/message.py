@@ -113,17 +113,30 @@ def _as_wire_f32(t: torch.Tensor) -> np.ndarray:
 _DIRECT_FILL_MIN = 1 << 20
 
 
+def _bind_pybytes():
+    """The two CPython entry points of _writable_bytes, bound ONCE (own function-pointer objects: ctypes.pythonapi's attributes are
+    shared process-wide, and re-declaring their signatures on every large response would race with other users of them)."""
+    if sys.implementation.name != "cpython":
+        return None
+    try:
+        new = ctypes.PYFUNCTYPE(ctypes.py_object, ctypes.c_void_p, ctypes.c_ssize_t)(("PyBytes_FromStringAndSize", ctypes.pythonapi))
+        ptr = ctypes.PYFUNCTYPE(ctypes.c_void_p, ctypes.py_object)(("PyBytes_AsString", ctypes.pythonapi))
+        return new, ptr
+    except Exception:   # pragma: no cover - exotic builds
+        return None
+
+
+_PYBYTES = _bind_pybytes()
+
+
 def _writable_bytes(n: int):
     """A new, uninitialised ``bytes`` object of length n and a writable uint8 view of its payload, or None where that is not
     available.  CPython's documented way to build a bytes object in place (PyBytes_FromStringAndSize(NULL, n), then fill the
     buffer PyBytes_AsString returns before anything else sees the object); the view must not outlive the fill."""
-    if sys.implementation.name != "cpython":
+    if _PYBYTES is None:
         return None
     try:
-        new = ctypes.pythonapi.PyBytes_FromStringAndSize
-        new.restype, new.argtypes = ctypes.py_object, [ctypes.c_void_p, ctypes.c_ssize_t]
-        ptr = ctypes.pythonapi.PyBytes_AsString
-        ptr.restype, ptr.argtypes = ctypes.c_void_p, [ctypes.py_object]
+        new, ptr = _PYBYTES
         obj = new(None, n)
         view = np.ctypeslib.as_array((ctypes.c_ubyte * n).from_address(ptr(obj)))
         return obj, view
@@ -177,7 +190,7 @@ class Response:
             for piece in pieces:
                 view[pos:pos + len(piece)] = np.frombuffer(piece, dtype=np.uint8)
                 pos += len(piece)
-        for shape, t in zip(shapes, tensors):
+        for bi, (shape, t) in enumerate(zip(shapes, tensors)):
             nd = len(shape)
             nbytes = 4 * math.prod(shape)
             block_head = _U32x2.pack(8 + 4 * nd + nbytes, nd) + struct.pack(f"<{nd}I", *shape)
@@ -189,7 +202,11 @@ class Response:
             view[pos:pos + len(block_head)] = np.frombuffer(block_head, dtype=np.uint8)
             pos += len(block_head)
             if nbytes:
-                view[pos:pos + nbytes] = _as_wire_f32(t).reshape(-1).view(np.uint8)
+                data = _as_wire_f32(t).reshape(-1).view(np.uint8)
+                if data.size != nbytes:    # the tensor changed shape after its slot was reserved (resize_ / set_ on a node output)
+                    raise Exception(f"output '{labels[bi]['channel']}' of node {labels[bi]['node']} changed size while the response was encoded "
+                                    f"({data.size} bytes for a block of {nbytes})")
+                view[pos:pos + nbytes] = data
                 pos += nbytes
         if fill is None:
             return b"".join(pieces)

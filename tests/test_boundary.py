@@ -271,3 +271,36 @@ def test_scan_nodes_discovers_plugins(tmp_path):
     finally:
         ctxmod.context().nodes.clear()
         ctxmod.context().nodes.update(before)
+
+
+def test_large_response_direct_fill_equals_join_with_empty_and_scalar_blocks(monkeypatch):
+    """the in-place fill of responses >= 1 MiB with an empty tensor and a 0-d tensor among the blocks gives the same
+    bytes as the joined form, and a tensor whose size no longer matches its reserved block ends in a clean exception (-> 400)."""
+    from interactive_vit_amd import message
+
+    def pin(**kw):
+        return Pinout(dict(kw))
+    g = Graph()
+    for k in range(4):
+        g.add_node("n", {})
+    big = torch.arange(300000, dtype=torch.float32).reshape(300, 1000)
+    g.nodes[0].set_pinout(pin(o=big))
+    g.nodes[1].set_pinout(pin(o=torch.zeros((0, 7), dtype=torch.float32)))
+    g.nodes[2].set_pinout(pin(o=torch.tensor(3.5)))
+    g.nodes[3].set_pinout(pin(o=torch.ones(5)))
+    direct = message.Response(g).encode()
+    assert len(direct) >= message._DIRECT_FILL_MIN
+    monkeypatch.setattr(message, "_DIRECT_FILL_MIN", 1 << 40)
+    joined = message.Response(g).encode()
+    assert direct == joined
+    outs = message.decode_response(direct)
+    assert [tuple(t.shape) for _, _, t in outs] == [(300, 1000), (0, 7), (), (5,)]
+
+    class Lying(torch.Tensor):                       # reports one shape when the slot is reserved, carries another
+        pass
+    monkeypatch.setattr(message, "_DIRECT_FILL_MIN", 1 << 20)
+    t = torch.Tensor._make_subclass(Lying, torch.zeros(300000))
+    t._ivit_shape = (300001,)
+    g.nodes[0].set_pinout(pin(o=t))
+    with pytest.raises(Exception, match="changed size"):
+        message.Response(g).encode()

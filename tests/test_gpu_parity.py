@@ -787,7 +787,7 @@ def test_dropped_pending_output_keeps_its_buffer_until_the_copy_has_landed(small
     for _ in range(4):
         out = eng.forward(img, 0, 2)
         assert isinstance(out, PendingTensor)
-        ptr, nbytes, ticket = out._ivit_ptr, out.numel() * 4, out._ivit_ticket
+        ptr, nbytes, ticket = out._ivit_ptr, int(np.prod(out._ivit_shape)) * 4, out._ivit_ticket   # (no torch call: that would wait)
         del out
         gc.collect()
         assert ticket in eng._held, "the engine must hold the buffer of a ticket nobody waited for"
