@@ -22,6 +22,7 @@
 // which makes those reads bank-conflict free.  Softmax statistics are fp32; row max / sum are wavefront shuffles across the 4 lane groups.
 #include "gemm_kernel.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace ivit {
 
@@ -81,7 +82,128 @@ __device__ __forceinline__ void att_stage(char* lds, const bf16_t* src0, int ld,
     }
 }
 
+// One 16-query block of one (image, head): S^T = K Q^T from the LDS image of K, single exact softmax pass in registers, O^T = V^T P^T with
+// V consumed row-major through ds_read_tr16_b64, normalise, store.  Shared by the one-head and the pipelined multi-head kernel.
 // OP: the 16-bit type of q|k|v, of the softmax numerators fed to P.V and of the output (OpBf16 / OpF16, common.h)
+template <int DH, int NKF, bool ODD, bool PROBS, class OP>
+__device__ __forceinline__ void att_block(const AttnParams& p, const char* k_lds, const char* v_lds, const bf16x8 (&qf)[AttLayout<DH, NKF, ODD>::KSTEPS],
+                                          int qbase, int b, int h, size_t row0, int N, int fr, int g, float cexp) {
+    using L = AttLayout<DH, NKF, ODD>;
+    constexpr int ATT_DH = DH;
+    const bf16x8 zero_frag = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int tq = fr >> 2, tp = fr & 3;   // transposed-read addressing: lane i = 4q + p of its 16-lane group supplies &V[key0 + q][d0 + 4p]
+    // ---- S^T = K Q^T
+    f32x4 s[NKF];
+#pragma unroll
+    for (int f = 0; f < NKF; ++f) {
+        if (ODD && f == NKF - 1) { s[f] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }   // no such rows in LDS: masked to -inf below
+        const int key = f * 16 + fr;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < L::KSTEPS; ++kk) {
+            // every lane reads (EXEC stays full); chunks past the head dim read the next row's
+            // bytes or the pad and are replaced by zeros
+            const int ch = kk * 4 + g;
+            bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + L::k_off(key, ch < L::CHUNKS ? ch : 0));
+            if (ch >= L::CHUNKS) kf = zero_frag;
+            a = OP::mfma(kf, qf[kk], a);
+        }
+        s[f] = a;
+    }
+
+    // ---- softmax over keys; only the last two fragments can hold padded keys (KEYS - N < 32)
+#pragma unroll
+    for (int f = NKF - 2; f < NKF; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (f * 16 + g * 4 + j >= N) s[f][j] = -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < NKF; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[f][0], s[f][1]), fmaxf(s[f][2], s[f][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * cexp;
+    float sum = 0.f;
+#pragma unroll
+    for (int f = 0; f < NKF; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[f][j], cexp, -mc));
+            s[f][j] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    if (PROBS) {   // lane holds P[q = qbase + fr][key = 16 f + 4 g + j]: a float4 per fragment
+        const int q = qbase + fr;
+        if (q < N) {
+            float* prow = p.probs + (((size_t)b * p.heads + h) * N + q) * N;
+#pragma unroll
+            for (int f = 0; f < NKF; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int key = f * 16 + g * 4 + j;
+                    if (key < N) prow[key] = s[f][j] * inv;
+                }
+        }
+        return;
+    }
+
+    // ---- O^T = V^T P^T
+    f32x4 o[L::NDB];
+#pragma unroll
+    for (int d = 0; d < L::NDB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < NKF / 2; ++st) {
+        const f32x4 p0 = s[2 * st], p1 = s[2 * st + 1];
+        union { bf16x8 v; unsigned int u[4]; } pk;
+        pk.u[0] = OP::pack2(p0[0], p0[1]);
+        pk.u[1] = OP::pack2(p0[2], p0[3]);
+        pk.u[2] = OP::pack2(p1[0], p1[1]);
+        pk.u[3] = OP::pack2(p1[2], p1[3]);
+        const int key_lo = 32 * st + 4 * g + tq;       // first half of the k-slots; second half = +16 keys
+#pragma unroll
+        for (int d = 0; d < L::NDB; ++d) {
+            const int chunk = d * 2 + (tp >> 1);       // 16-B chunk of columns d*16 + 4*tp
+            const char* lo = v_lds + L::v_off(key_lo, chunk) + (tp & 1) * 8;
+            const char* hi = v_lds + L::v_off(key_lo + 16, chunk) + (tp & 1) * 8;
+            union { bf16x8 v; bf16x4 h2[2]; } vf;
+            vf.h2[0] = lds_read_tr16(lo);
+            if (ODD && st == NKF / 2 - 1) vf.h2[1] = bf16x4{0, 0, 0, 0};   // the fragment that is not in LDS: its P is exactly 0
+            else vf.h2[1] = lds_read_tr16(hi);
+            o[d] = OP::mfma(vf.v, pk.v, o[d]);
+        }
+    }
+
+    // ---- normalise and store: lane holds O[qbase + fr][16 d + 4 g .. +3]
+    // (the guard diverges only here, after the last transposed read of this block, which needs
+    // EXEC all ones; the next block's reads run with the full mask again)
+    const int q = qbase + fr;
+    if (q < N && p.out8) {   // fp8 data path: 4 consecutive d -> one dword of e4m3
+        unsigned char* orow8 = p.out8 + (row0 + q) * p.ldo8 + h * ATT_DH + g * 4;
+        const float sc = inv * p.scale8;
+#pragma unroll
+        for (int d = 0; d < L::NDB; ++d)
+            *reinterpret_cast<unsigned int*>(orow8 + d * 16) = pack_fp8x4(o[d][0] * sc, o[d][1] * sc, o[d][2] * sc, o[d][3] * sc);
+    } else if (q < N) {
+        bf16_t* orow = p.out + (row0 + q) * p.ldo + h * ATT_DH + g * 4;
+#pragma unroll
+        for (int d = 0; d < L::NDB; ++d) {
+            u32x2 pk2 = {OP::pack2(o[d][0] * inv, o[d][1] * inv), OP::pack2(o[d][2] * inv, o[d][3] * inv)};
+            *reinterpret_cast<u32x2*>(orow + d * 16) = pk2;
+            if (p.lo_off) {   // low parts for the split-operand out-projection (wave-uniform)
+                float lo[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lo[r] = o[d][r] * inv - OP::to_f32(OP::from_f32(o[d][r] * inv));
+                u32x2 pl = {OP::pack2(lo[0], lo[1]), OP::pack2(lo[2], lo[3])};
+                *reinterpret_cast<u32x2*>(orow + p.lo_off + d * 16) = pl;
+            }
+        }
+    }
+}
+
 template <int DH, int NKF, bool ODD, bool PROBS, class OP>
 __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     using L = AttLayout<DH, NKF, ODD>;
@@ -121,9 +243,6 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed; the barrier publishes everyone's
     __syncthreads();
-
-    // transposed-read addressing: lane i = 4q + p of its 16-lane group supplies &V[key0 + q][d0 + 4p]
-    const int tq = fr >> 2, tp = fr & 3;
     const float cexp = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*scale*log2 e)
 
     // The wave's 16-query blocks (wave, wave + nwaves, ...) run one after the other, so only one block's
@@ -140,116 +259,68 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
                 qf[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
                              ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8) : zero_frag;
         }
+        att_block<DH, NKF, ODD, PROBS, OP>(p, k_lds, v_lds, qf, qbase, b, h, row0, N, fr, g, cexp);
+    }
+}
 
-        // ---- S^T = K Q^T
-        f32x4 s[NKF];
+// Pipelined form for short sequences (every wave owns exactly ONE 16-query block: tokens <= 16 x waves <= 256): a workgroup handles ITEMS
+// consecutive heads of one image, K / V double buffered in LDS.  The one-head kernel puts 768 workgroups on the chip at once (ViT-B/16,
+// B = 64): all of them stage 58 MB first, then all compute, then all store - three phases of a 24 us launch with the memory system idle
+// in the middle one.  Here the staging of head i + 1 (and its Q fragments) is in flight under the math of head i.
+template <int DH, int NKF, bool ODD, class OP>
+__global__ __launch_bounds__(1024) void ivit_attention_pipe(AttnParams p, int items) {
+    using L = AttLayout<DH, NKF, ODD>;
+    constexpr int ATT_DH = DH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h0 = blockIdx.y * items;
+    const int N = p.tokens;
+    const int D = p.heads * ATT_DH;
+    const size_t row0 = (size_t)b * N;
+    const bf16_t* qkv = p.qkv;
+    const int ld = p.ldqkv;
+    const int nwaves = blockDim.x >> 6;
+    const int qbase = wave * 16;                          // this wave's block (waves past the last block only help staging)
+    const bool has_block = qbase < N;
+    const float cexp = p.scale * 1.44269504088896340736f;
+    const bf16x8 zero_frag = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int nh = min(items, p.heads - h0);
+
+    auto stage = [&](int h, int buf) {
+        char* base = smem + buf * L::LDS_BYTES;
+        att_stage<L>(base, qkv + row0 * ld + h * ATT_DH + D, ld, N, L::K_SWZ, wave, nwaves, lane);
+        att_stage<L>(base + L::K_BYTES, qkv + row0 * ld + h * ATT_DH + 2 * D, ld, N, L::V_SWZ, wave, nwaves, lane);
+    };
+    auto load_q = [&](int h, bf16x8 (&q)[L::KSTEPS]) {
+        const int qrow = min(qbase + fr, N - 1);
 #pragma unroll
-        for (int f = 0; f < NKF; ++f) {
-            if (ODD && f == NKF - 1) { s[f] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }   // no such rows in LDS: masked to -inf below
-            const int key = f * 16 + fr;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < L::KSTEPS; ++kk)
+            q[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
+                        ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8) : zero_frag;
+    };
+
+    bf16x8 qf[L::KSTEPS], qn[L::KSTEPS];
+    stage(h0, 0);
+    load_q(h0, qn);
+    for (int it = 0; it < nh; ++it) {
+        // head it: its K / V image and Q fragments have landed (every vector-memory operation of this wave is behind us); the barrier
+        // publishes everyone's pieces and says that every wave is done with the OTHER buffer (head it - 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-            for (int kk = 0; kk < L::KSTEPS; ++kk) {
-                // every lane reads (EXEC stays full); chunks past the head dim read the next row's
-                // bytes or the pad and are replaced by zeros
-                const int ch = kk * 4 + g;
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(k_lds + L::k_off(key, ch < L::CHUNKS ? ch : 0));
-                if (ch >= L::CHUNKS) kf = zero_frag;
-                a = OP::mfma(kf, qf[kk], a);
-            }
-            s[f] = a;
+        for (int kk = 0; kk < L::KSTEPS; ++kk) qf[kk] = qn[kk];
+        if (it + 1 < nh) {
+            // register loads FIRST, then the DMA: hipcc waits for everything in flight at the first use of a register load, and that
+            // use is the copy above, one iteration later, behind the wait that this loop needs anyway
+            load_q(h0 + it + 1, qn);
+            stage(h0 + it + 1, (it + 1) & 1);
         }
-
-        // ---- softmax over keys; only the last two fragments can hold padded keys (KEYS - N < 32)
-#pragma unroll
-        for (int f = NKF - 2; f < NKF; ++f)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (f * 16 + g * 4 + j >= N) s[f][j] = -INFINITY;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int f = 0; f < NKF; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[f][0], s[f][1]), fmaxf(s[f][2], s[f][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mc = mx * cexp;
-        float sum = 0.f;
-#pragma unroll
-        for (int f = 0; f < NKF; ++f)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[f][j], cexp, -mc));
-                s[f][j] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-
-        if (PROBS) {   // lane holds P[q = qbase + fr][key = 16 f + 4 g + j]: a float4 per fragment
-            const int q = qbase + fr;
-            if (q < N) {
-                float* prow = p.probs + (((size_t)b * p.heads + h) * N + q) * N;
-#pragma unroll
-                for (int f = 0; f < NKF; ++f)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int key = f * 16 + g * 4 + j;
-                        if (key < N) prow[key] = s[f][j] * inv;
-                    }
-            }
-            continue;
-        }
-
-        // ---- O^T = V^T P^T
-        f32x4 o[L::NDB];
-#pragma unroll
-        for (int d = 0; d < L::NDB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int st = 0; st < NKF / 2; ++st) {
-            const f32x4 p0 = s[2 * st], p1 = s[2 * st + 1];
-            union { bf16x8 v; unsigned int u[4]; } pk;
-            pk.u[0] = OP::pack2(p0[0], p0[1]);
-            pk.u[1] = OP::pack2(p0[2], p0[3]);
-            pk.u[2] = OP::pack2(p1[0], p1[1]);
-            pk.u[3] = OP::pack2(p1[2], p1[3]);
-            const int key_lo = 32 * st + 4 * g + tq;       // first half of the k-slots; second half = +16 keys
-#pragma unroll
-            for (int d = 0; d < L::NDB; ++d) {
-                const int chunk = d * 2 + (tp >> 1);       // 16-B chunk of columns d*16 + 4*tp
-                const char* lo = v_lds + L::v_off(key_lo, chunk) + (tp & 1) * 8;
-                const char* hi = v_lds + L::v_off(key_lo + 16, chunk) + (tp & 1) * 8;
-                union { bf16x8 v; bf16x4 h2[2]; } vf;
-                vf.h2[0] = lds_read_tr16(lo);
-                if (ODD && st == NKF / 2 - 1) vf.h2[1] = bf16x4{0, 0, 0, 0};   // the fragment that is not in LDS: its P is exactly 0
-                else vf.h2[1] = lds_read_tr16(hi);
-                o[d] = OP::mfma(vf.v, pk.v, o[d]);
-            }
-        }
-
-        // ---- normalise and store: lane holds O[qbase + fr][16 d + 4 g .. +3]
-        // (the guard diverges only here, after the last transposed read of this block, which needs
-        // EXEC all ones; the next block's reads run with the full mask again)
-        const int q = qbase + fr;
-        if (q < N && p.out8) {   // fp8 data path: 4 consecutive d -> one dword of e4m3
-            unsigned char* orow8 = p.out8 + (row0 + q) * p.ldo8 + h * ATT_DH + g * 4;
-            const float sc = inv * p.scale8;
-#pragma unroll
-            for (int d = 0; d < L::NDB; ++d)
-                *reinterpret_cast<unsigned int*>(orow8 + d * 16) = pack_fp8x4(o[d][0] * sc, o[d][1] * sc, o[d][2] * sc, o[d][3] * sc);
-        } else if (q < N) {
-            bf16_t* orow = p.out + (row0 + q) * p.ldo + h * ATT_DH + g * 4;
-#pragma unroll
-            for (int d = 0; d < L::NDB; ++d) {
-                u32x2 pk2 = {OP::pack2(o[d][0] * inv, o[d][1] * inv), OP::pack2(o[d][2] * inv, o[d][3] * inv)};
-                *reinterpret_cast<u32x2*>(orow + d * 16) = pk2;
-                if (p.lo_off) {   // low parts for the split-operand out-projection (wave-uniform)
-                    float lo[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) lo[r] = o[d][r] * inv - OP::to_f32(OP::from_f32(o[d][r] * inv));
-                    u32x2 pl = {OP::pack2(lo[0], lo[1]), OP::pack2(lo[2], lo[3])};
-                    *reinterpret_cast<u32x2*>(orow + p.lo_off + d * 16) = pl;
-                }
-            }
+        asm volatile("" ::: "memory");
+        if (has_block) {
+            const char* k_lds = smem + (it & 1) * L::LDS_BYTES;
+            att_block<DH, NKF, ODD, false, OP>(p, k_lds, k_lds + L::K_BYTES, qf, qbase, b, h0 + it, row0, N, fr, g, cexp);
         }
     }
 }
@@ -271,6 +342,19 @@ static hipError_t launch_nkf_op(const AttnParams& p, hipStream_t stream) {
     // which the 53-KiB ODD image allows - against two of 7-8 waves: 0.333 vs 0.307 ms per 12 launches; the
     // launch moves 58 + 19 MB in 25 us and is bound by that, not by the 1.5-round grid.  Round 2, same question with up to 13
     // waves - one 16-query block each, one workgroup per CU: 5 / 7 / 8 / 10 / 13 waves -> 0.372 / 0.315 / 0.312 / 0.344 / 0.354 ms.)
+    // pipelined multi-head form: every wave owns one query block, two K / V images fit LDS, several heads per image
+    if (!PROBS && blocks <= 16 && 2 * L::LDS_BYTES <= 160 * 1024 && p.heads >= 2) {
+        static const int pipe = [] { const char* v = getenv("IVIT_ATTN_PIPE"); return v ? atoi(v) : 1; }();   // IVIT_ATTN_PIPE=0: measurement knob
+        if (pipe) {
+            const int items = p.heads % 3 == 0 ? 3 : (p.heads % 4 == 0 ? 4 : 2);
+            auto kernel = ivit_attention_pipe<DH, NKF, ODD, OP>;
+            e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), 2 * L::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            dim3 pgrid(1, ceil_div(p.heads, items), p.batch);
+            hipLaunchKernelGGL(kernel, pgrid, dim3(blocks * 64), 2 * L::LDS_BYTES, stream, p, items);
+            return hipGetLastError();
+        }
+    }
     const int waves = std::min(8, blocks);
     dim3 grid(1, p.heads, p.batch);
     hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, ODD, PROBS, OP>), grid, dim3(waves * 64), L::LDS_BYTES, stream, p);
