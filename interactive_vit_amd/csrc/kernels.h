@@ -76,6 +76,9 @@ const char* gemm_fp8_kernel_name(const GemmParams& p);
 // ---------------------------------------------------------------- attention (kernels_attn.hip)
 struct AttnParams {
     const bf16_t* qkv; int ldqkv;  // [B*N, 3D] bf16: q | k | v, head h at columns h*dh
+    // head-major form (both 0 = the row-major form above): element (which in q/k/v, head h, token row r, d) lives at
+    // qkv + which * which_stride + h * head_stride + r * ldqkv + d, with ldqkv = dh: a head's K / V rows are contiguous in memory
+    int64_t head_stride, which_stride;
     bf16_t* out; int ldo;          // [B*N, D] bf16
     int batch, tokens, heads, head_dim;
     float scale;                   // 1/sqrt(dh)

@@ -227,8 +227,9 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     const int q0 = wave * 16;
 
     // ---- K and V by LDS-DMA (row-major, 16-B chunks, swizzle applied on the source address)
-    att_stage<L>(k_lds, qkv + row0 * ld + h * ATT_DH + D, ld, N, L::K_SWZ, wave, nwaves, lane);
-    att_stage<L>(v_lds, qkv + row0 * ld + h * ATT_DH + 2 * D, ld, N, L::V_SWZ, wave, nwaves, lane);
+    const size_t hs = p.head_stride ? (size_t)p.head_stride : (size_t)ATT_DH, ws = p.which_stride ? (size_t)p.which_stride : (size_t)D;
+    att_stage<L>(k_lds, qkv + row0 * ld + h * hs + ws, ld, N, L::K_SWZ, wave, nwaves, lane);
+    att_stage<L>(v_lds, qkv + row0 * ld + h * hs + 2 * ws, ld, N, L::V_SWZ, wave, nwaves, lane);
 
     // ---- Q fragments of the wave's first query block, behind the DMA queue so that their latency
     // overlaps the staging (B operand: lane holds Q[q + fr][kk*32 + 8g .. +7])
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
 #pragma unroll
         for (int kk = 0; kk < L::KSTEPS; ++kk)
             qf[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
-                         ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8) : zero_frag;
+                         ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * hs + kk * 32 + g * 8) : zero_frag;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed; the barrier publishes everyone's
     __syncthreads();
@@ -257,12 +258,14 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
 #pragma unroll
             for (int kk = 0; kk < L::KSTEPS; ++kk)
                 qf[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
-                             ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8) : zero_frag;
+                             ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * hs + kk * 32 + g * 8) : zero_frag;
         }
         att_block<DH, NKF, ODD, PROBS, OP>(p, k_lds, v_lds, qf, qbase, b, h, row0, N, fr, g, cexp);
     }
 }
 
+#ifdef IVIT_GEMM_ABLATIONS   // study kernel (round 3): correct, 8 % slower than the one-head kernel (25.5 against 23.6 us in a forward, tools/fused_bench
+// with IVIT_ATTN_PIPE=1); kept out of libivit.so
 // Pipelined form for short sequences (every wave owns exactly ONE 16-query block: tokens <= 16 x waves <= 256): a workgroup handles ITEMS
 // consecutive heads of one image, K / V double buffered in LDS.  The one-head kernel puts 768 workgroups on the chip at once (ViT-B/16,
 // B = 64): all of them stage 58 MB first, then all compute, then all store - three phases of a 24 us launch with the memory system idle
@@ -287,18 +290,19 @@ __global__ __launch_bounds__(1024) void ivit_attention_pipe(AttnParams p, int it
     const float cexp = p.scale * 1.44269504088896340736f;
     const bf16x8 zero_frag = {0, 0, 0, 0, 0, 0, 0, 0};
     const int nh = min(items, p.heads - h0);
+    const size_t hs = p.head_stride ? (size_t)p.head_stride : (size_t)ATT_DH, ws = p.which_stride ? (size_t)p.which_stride : (size_t)D;
 
     auto stage = [&](int h, int buf) {
         char* base = smem + buf * L::LDS_BYTES;
-        att_stage<L>(base, qkv + row0 * ld + h * ATT_DH + D, ld, N, L::K_SWZ, wave, nwaves, lane);
-        att_stage<L>(base + L::K_BYTES, qkv + row0 * ld + h * ATT_DH + 2 * D, ld, N, L::V_SWZ, wave, nwaves, lane);
+        att_stage<L>(base, qkv + row0 * ld + h * hs + ws, ld, N, L::K_SWZ, wave, nwaves, lane);
+        att_stage<L>(base + L::K_BYTES, qkv + row0 * ld + h * hs + 2 * ws, ld, N, L::V_SWZ, wave, nwaves, lane);
     };
     auto load_q = [&](int h, bf16x8 (&q)[L::KSTEPS]) {
         const int qrow = min(qbase + fr, N - 1);
 #pragma unroll
         for (int kk = 0; kk < L::KSTEPS; ++kk)
             q[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
-                        ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * ATT_DH + kk * 32 + g * 8) : zero_frag;
+                        ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * hs + kk * 32 + g * 8) : zero_frag;
     };
 
     bf16x8 qf[L::KSTEPS], qn[L::KSTEPS];
@@ -325,6 +329,8 @@ __global__ __launch_bounds__(1024) void ivit_attention_pipe(AttnParams p, int it
     }
 }
 
+#endif
+
 bool attention_supported(int tokens, int head_dim) {
     if (tokens < 1) return false;
     if (head_dim == 64) return tokens <= 38 * 16;
@@ -342,9 +348,10 @@ static hipError_t launch_nkf_op(const AttnParams& p, hipStream_t stream) {
     // which the 53-KiB ODD image allows - against two of 7-8 waves: 0.333 vs 0.307 ms per 12 launches; the
     // launch moves 58 + 19 MB in 25 us and is bound by that, not by the 1.5-round grid.  Round 2, same question with up to 13
     // waves - one 16-query block each, one workgroup per CU: 5 / 7 / 8 / 10 / 13 waves -> 0.372 / 0.315 / 0.312 / 0.344 / 0.354 ms.)
+#ifdef IVIT_GEMM_ABLATIONS
     // pipelined multi-head form: every wave owns one query block, two K / V images fit LDS, several heads per image
     if (!PROBS && blocks <= 16 && 2 * L::LDS_BYTES <= 160 * 1024 && p.heads >= 2) {
-        static const int pipe = [] { const char* v = getenv("IVIT_ATTN_PIPE"); return v ? atoi(v) : 1; }();   // IVIT_ATTN_PIPE=0: measurement knob
+        static const int pipe = [] { const char* v = getenv("IVIT_ATTN_PIPE"); return v ? atoi(v) : 0; }();   // IVIT_ATTN_PIPE=1 selects it
         if (pipe) {
             const int items = p.heads % 3 == 0 ? 3 : (p.heads % 4 == 0 ? 4 : 2);
             auto kernel = ivit_attention_pipe<DH, NKF, ODD, OP>;
@@ -355,6 +362,7 @@ static hipError_t launch_nkf_op(const AttnParams& p, hipStream_t stream) {
             return hipGetLastError();
         }
     }
+#endif
     const int waves = std::min(8, blocks);
     dim3 grid(1, p.heads, p.batch);
     hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, ODD, PROBS, OP>), grid, dim3(waves * 64), L::LDS_BYTES, stream, p);

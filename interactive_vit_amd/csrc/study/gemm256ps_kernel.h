@@ -129,7 +129,7 @@ __device__ __forceinline__ void gemm256ps_body(const GemmParams& p, char* smem) 
     if (tile >= num_tiles) return;   // never: the host launches G <= num_tiles
 
     G256PCtx c;
-    c.smem = smem; c.wave = wave; c.lda = p.lda; c.ldw = p.ldw; c.a_wrap = p.a_wrap; c.nt = p.K / GEMM_BK;
+    c.smem = smem; c.wave = wave; c.lda = p.lda; c.ldw = p.ldw; c.nt = p.K / GEMM_BK;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         c.a_rd[kk] = (wr * 64 + fr) * 128 + (((kk * 4 + fq) ^ (fr & 7)) << 4);

@@ -70,6 +70,24 @@ int main(int argc, char** argv) {
     auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     printf("B=%d: qkv GEMM %.1f us + attention %.1f us = %.1f us;  fused %.1f us (debug %d)\n", B, med(tg), med(ta), med(tg) + med(ta), med(tf), f.debug);
 
+    {   // attention alone: row-major q|k|v [M, 3D] against the head-major form (a head's K / V rows contiguous), warm (the same 58 MB
+        // re-read) and cold (a 768 MB fill between launches evicts L2 and the Infinity Cache); timing only - head-major reads the
+        // same buffer with other strides
+        AttnParams hm = ap; hm.ldqkv = 64; hm.head_stride = (int64_t)Mp * 64; hm.which_stride = (int64_t)H * Mp * 64;
+        void* junk; const size_t junk_bytes = (size_t)768 << 20; CK(hipMalloc(&junk, junk_bytes));
+        for (int cold = 0; cold < 2; ++cold)
+            for (int lay = 0; lay < 2; ++lay) {
+                const AttnParams& q = lay ? hm : ap;
+                std::vector<float> t;
+                for (int r = 0; r < 15; ++r) {
+                    if (cold) CK(hipMemsetAsync(junk, r, junk_bytes, 0));
+                    float ms; CK(hipEventRecord(e0, 0)); CK(launch_attention(q, 0)); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms * 1000.f);
+                }
+                printf("attention alone, %s q|k|v, %s caches: median %.1f us\n", lay ? "head-major" : "row-major ", cold ? "cold" : "warm", med(t));
+            }
+        CK(hipFree(junk));
+    }
     CK(hipMemset(stamps, 0, (size_t)grid * 128 * 8));
     FusedQkvAttnArgs fs = f; fs.stamps = stamps;
     CK(launch_fused_qkv_attention(fs, 0)); CK(hipDeviceSynchronize());
