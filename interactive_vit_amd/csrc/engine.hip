@@ -362,9 +362,11 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
 
     if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); }
     {
-        // IVIT_SPLIT=2 runs the two halves of a batch on two streams.  Measured on MI355X (ViT-B/16,
-        // B=64): kernels overlap (their durations double) but images/s does not move (19.0k vs 18.9k) -
-        // all kernels queue on the same per-CU vector-memory path - so it is off by default.
+        // IVIT_SPLIT=2 runs the two halves of a batch on two streams.  Measured on MI355X: with LayerNorm
+        // kernels +2-2.5 % at ViT-B/16 B = 64 (+5 % at B = 128 / 256, -9 % at B = 16, -2.5 ... -6 % on ViT-L / ViT-H); with the
+        // LayerNorm fold of section 3a (the default) the B = 64 gain is gone (19 563 vs 19 516 img/s; round 3, as independent
+        // lanes: 20 012-20 412 against 20 561-20 612), and overlapping kernels make the per-kernel roofline accounting of bench.py
+        // measure the overlap instead of the kernels - so it is off by default.
         const char* sp = getenv("IVIT_SPLIT");
         e->split = sp ? atoi(sp) : 1;
         const char* gr = getenv("IVIT_GRAPHS");

@@ -514,7 +514,7 @@ def test_head_dim_80_and_patch_14_small():
 
 def test_vit_h14_bf16_shapes():
     """BASELINE config 5's MODEL (ViT-H/14: 257 tokens, D = 1280, 16 heads of 80, MLP 5120, K = 588) in
-    bf16 - the fp8 data path of that config is not built yet (out of scope list)."""
+    bf16 (the fp8 data path of that config has its own tests: tests/test_gpu_configs.py, test_config5_*)."""
     from interactive_vit_amd.engine import Engine
     from oracle import vit_oracle
     cfg = VARIANTS["vit_h_14"]
