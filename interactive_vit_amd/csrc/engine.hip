@@ -609,9 +609,10 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
     if (lf) { p.ln_part = lf->part; p.ln_stats = lf->stats; p.xb = lf->xb; p.ldxb = e->D; p.ln_s = lf->s; p.ln_eps = e->cfg.ln_eps; p.ln_dim = e->D; }
     const bool bf_out = (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16 || epi == EPI_LNFOLD_BF16 || epi == EPI_LNFOLD_GELU_BF16);
     const bool resid_in = (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_RESID_STATS);
+    const bool stats_out = (epi == EPI_BIAS_RESID_STATS || epi == EPI_BIAS_ROWADD_STATS);
     const double flops = 2.0 * M * (double)W.rows * W.cols;
     const double bytes = 2.0 * ((double)M * W.cols + (double)W.rows * W.cols) + (double)M * W.rows * (bf_out ? 2 : 4) +
-                         (resid_in ? 4.0 * M * W.rows : 0.0) + (epi == EPI_BIAS_RESID_STATS ? 2.0 * M * W.rows : 0.0);
+                         (resid_in ? 4.0 * M * W.rows : 0.0) + (stats_out ? 2.0 * M * W.rows : 0.0);
     ProfScope ps(e, PC_GEMM, st, flops, bytes, role, gemm_kernel_name(p));
     HIP_TRY(launch_gemm(p, st));
     return 0;
@@ -780,7 +781,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
     const int L = e->cfg.layers, D = e->D, N = e->N, Np = e->Np;
     const int ST_LN = ST_LAYER0 + L, ST_CLS = ST_LN + 1, ST_HEADS = ST_LN + 2;
     const float* cur = in;
-    bool in_x = false, patches_ready = false;
+    bool in_x = false, patches_ready = false, stats_from_patch = false;
     int s = begin;
 
     if (s == ST_TRANSFORM) {
@@ -804,12 +805,20 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         if (end == ST_CONV + 1)
             return run_gemm(e, st, w.patches, e->ld_patch, e->w_patch, B * Np, e->b_patch, EPI_BIAS_F32, out, D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "patch");
         // conv_proj + tokens fused: the GEMM epilogue scatters rows to token 1+n of each image and adds
-        // the position embedding; a small kernel writes the class rows
-        if (run_gemm(e, st, w.patches, e->ld_patch, e->w_patch, B * Np, e->b_patch, EPI_BIAS_ROWADD_F32,
-                     (end == ST_TOKENS + 1) ? out : w.x, D, nullptr, 0, e->pos, D, Np, N, 1, nullptr, "patch")) return 1;
+        // the position embedding; a small kernel writes the class rows.  In front of a LayerNorm-folded first layer the same epilogue
+        // also leaves the statistics pairs and the 16-bit copy of the token rows (round 3: ivit_row_stats_pairs then only visits the
+        // B class rows instead of re-reading the whole stream: 15.7 us -> 2 us at ViT-B/16 B = 64)
+        stats_from_patch = end > ST_LAYER0 && e->cfg.layers > 0 && !e->ratio_on && e->cfg.precision != IVIT_PRECISION_FP8 && fold_for_rows(e, B * N);
+        LnFold pfold; pfold.part = w.ln_part; pfold.xb = w.h;
+        if (run_gemm(e, st, w.patches, e->ld_patch, e->w_patch, B * Np, e->b_patch, stats_from_patch ? EPI_BIAS_ROWADD_STATS : EPI_BIAS_ROWADD_F32,
+                     (end == ST_TOKENS + 1) ? out : w.x, D, nullptr, 0, e->pos, D, Np, N, 1, stats_from_patch ? &pfold : nullptr, "patch")) return 1;
         {
             ProfScope ps(e, PC_OTHER, st, 0.0, 8.0 * B * D);
             HIP_TRY(launch_tokens(nullptr, e->cls_tok, e->pos, (end == ST_TOKENS + 1) ? out : w.x, B, Np, D, st));
+        }
+        if (stats_from_patch) {
+            ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)B * D * 6.0);
+            HIP_TRY(launch_row_stats(w.x, D, B, D, w.h, D, w.ln_part, st, e->f16, N));
         }
         if (end == ST_TOKENS + 1) return 0;
         in_x = true;
@@ -825,7 +834,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         in_x = true;
         s = ST_LAYER0;
     }
-    bool stats_ready = stats_in_first && s == begin && !in_x && fold_for_rows(e, B * N);   // LayerNorm fold: x's statistics pairs and 16-bit copy are in the workspace
+    bool stats_ready = (stats_in_first && s == begin && !in_x && fold_for_rows(e, B * N)) || stats_from_patch;   // LayerNorm fold: x's statistics pairs and 16-bit copy are in the workspace
     for (; s < end && s < ST_LN; ++s) {
         // the first layer of a range that starts on the caller's tensor reads it in place; the last layer of a range that ends on an
         // encoder layer writes the caller's output (no copies of the stream into / out of w.x)

@@ -226,7 +226,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 
 // ---- LayerNorm-fold epilogues (their own kernel instantiations: the classic kernels stay as they are).
 // EPI_BIAS_RESID_STATS: residual add as EPI_BIAS_RESID_F32; additionally the bf16 copy of the new rows and, per row,
-// the (sum, M2 about the local mean) of this wave's 64 columns -> ln_part[row][n_base / 64].
+// the (sum, M2 about the local mean) of this wave's 64 columns -> ln_part[row][n_base / 64].  EPI_BIAS_ROWADD_STATS: the same with the
+// addend taken from a table row and the output row remapped (grp_in / grp_out / grp_off as EPI_BIAS_ROWADD_F32; x + y = y + x bit for bit).
 // (Round 3: the residual rows loaded at the START of the kernel into 80 registers, so that the epilogue only adds and stores, was measured and
 // removed: vmcnt counts in issue order, so the K loop's first wait also waits for those loads - 38.7 MB from every CU at once, 8 us -
 // and the launch got slower: proj 33 -> 49 us in a forward.)
@@ -246,8 +247,15 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
     for (int i = 0; i < T::FM; ++i) {
         const int m = m_base + i * 16 + fr;
         const bool row_ok = INTERIOR || m < p.M;
-        const int mr = row_ok ? m : p.M - 1;
-        const float* rs = p.resid + (size_t)mr * p.ldr;
+        int mr = row_ok ? m : p.M - 1;
+        const float* rs;
+        if (p.grp_in > 0) {   // EPI_BIAS_ROWADD_STATS: GEMM row -> token row of its image, the addend is the table row (position embedding)
+            const int grp = mr / p.grp_in, within = mr - grp * p.grp_in;
+            mr = grp * p.grp_out + p.grp_off + within;
+            rs = p.rowadd + (size_t)(p.grp_off + within) * p.ldra;
+        } else {
+            rs = p.resid + (size_t)mr * p.ldr;
+        }
         float4 x[T::FN];
 #pragma unroll
         for (int j = 0; j < T::FN; ++j) {
@@ -285,7 +293,7 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
         }
         m2 += __shfl_xor(m2, 16, 64);
         m2 += __shfl_xor(m2, 32, 64);
-        if (fq == 0 && row_ok && ncols > 0) p.ln_part[(size_t)m * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
+        if (fq == 0 && row_ok && ncols > 0) p.ln_part[(size_t)mr * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
     }
 }
 

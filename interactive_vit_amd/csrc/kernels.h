@@ -20,6 +20,8 @@ enum GemmEpilogue : int {
     EPI_BIAS_RESID_STATS = 6,   // EPI_BIAS_RESID_F32, plus xb = bf16(out) and the row statistics of out for the NEXT GEMM
     EPI_LNFOLD_BF16 = 7,        // out(bf16) = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n]        (A = bf16(x), W = bf16(W . gamma))
     EPI_LNFOLD_GELU_BF16 = 8,   // out(bf16) = gelu_erf(the same)
+    EPI_BIAS_ROWADD_STATS = 9,  // EPI_BIAS_ROWADD_F32 (row remap + table add), plus xb and the row statistics as EPI_BIAS_RESID_STATS: the patch
+                                // embedding in front of a LayerNorm-folded first layer (no ivit_row_stats_pairs pass over the token stream)
 };
 
 struct GemmParams {
@@ -139,7 +141,7 @@ hipError_t launch_scale_vec(const float* in, float a, float* out, int n, hipStre
 constexpr int GEMM_LN_SLOTS = 32;   // 64-column statistics slots per row (dim <= 2048)
 hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, const float* gamma, const float* beta, const float* bias,
                                   bf16_t* wf, float* s_out, float* c_out, hipStream_t s, int f16 = 0);
-hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16 = 0);   // part: [rows][GEMM_LN_SLOTS] (sum, M2) pairs, as EPI_BIAS_RESID_STATS writes them
+hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16 = 0, int row_step = 1);   // part: [rows][GEMM_LN_SLOTS] (sum, M2) pairs, as EPI_BIAS_RESID_STATS writes them
 // atomicMax(*out, max over rows of |mean| / sqrt(var + eps)) of a [rows, dim] f32 matrix; the caller zeroes *out
 hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, float eps, float* out, hipStream_t s);
 // strided row gather: out[i,:] = in[i*row_stride, :dim]  (the `cls` node)

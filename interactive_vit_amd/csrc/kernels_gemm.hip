@@ -397,10 +397,11 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
     if (p.K <= 0 || p.K % GEMM_BK != 0) return hipErrorInvalidValue;
     if ((p.lda % 8) || (p.ldw % 8)) return hipErrorInvalidValue;   // 16-B aligned rows for the DMA
     if ((p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
-    const int family = p.epi == EPI_BIAS_RESID_STATS ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
+    const int family = (p.epi == EPI_BIAS_RESID_STATS || p.epi == EPI_BIAS_ROWADD_STATS) ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
     if (family) {   // LayerNorm-fold epilogues: their own instantiations of the product tiles
-        if (p.grp_in != 0) return hipErrorInvalidValue;
-        if (family == 1 && (!p.ln_part || !p.resid || !p.xb || (p.ldxb % 4))) return hipErrorInvalidValue;
+        const bool remap = p.epi == EPI_BIAS_ROWADD_STATS;
+        if ((p.grp_in != 0) != remap) return hipErrorInvalidValue;
+        if (family == 1 && (!p.ln_part || !(remap ? p.rowadd : p.resid) || !p.xb || (p.ldxb % 4) || (remap && (p.ldra % 4)))) return hipErrorInvalidValue;
         if (family == 2 && ((!p.ln_stats && !p.ln_part) || !p.ln_s || p.ln_dim <= 0 || p.ln_dim > 64 * GEMM_LN_SLOTS)) return hipErrorInvalidValue;
     }
 #ifdef IVIT_GEMM_ABLATIONS
@@ -448,7 +449,7 @@ const char* gemm_fp8_kernel_name(const GemmParams& p) {
 
 const char* gemm_kernel_name(const GemmParams& p) {
     const int v = gemm_pick_variant(p.M, p.N, p.K);
-    const int family = p.epi == EPI_BIAS_RESID_STATS ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
+    const int family = (p.epi == EPI_BIAS_RESID_STATS || p.epi == EPI_BIAS_ROWADD_STATS) ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
     static const char* names[2][5][3] = {
         {{"ivit_gemm_bf16_64x128x64_deep", "ivit_gemm_bf16_64x128x64_deep_rs", "ivit_gemm_bf16_64x128x64_deep_lf"},
          {"ivit_gemm_bf16_128x128x64_sb", "ivit_gemm_bf16_128x128x64_sb_rs", "ivit_gemm_bf16_128x128x64_sb_lf"},

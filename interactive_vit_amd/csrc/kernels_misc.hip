@@ -340,13 +340,14 @@ hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, c
 // in that order - so a layer gives the same bits whether its input came out of the previous layer's MLP-down GEMM in the same call,
 // out of an earlier call (chained nodes, which then skip this kernel) or from the caller.
 __global__ __launch_bounds__(256) void ivit_row_stats_pairs(const float* __restrict__ x, int ldx, int rows, int dim, bf16_t* __restrict__ xb, int ldxb,
-                                                            float2* __restrict__ part, int f16) {
+                                                            float2* __restrict__ part, int f16, int row_step) {
     const int nslots = (dim + 63) >> 6, per_row = nslots * 4;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int row = (int)(t / per_row);
     const int rem = (int)(t - (int64_t)row * per_row), slot = rem >> 2, fq = rem & 3;
     const bool live = row < rows;
     if (!live) row = rows - 1;                 // every lane stays for the shuffles
+    row *= row_step;                           // (row_step = tokens: the class rows of a batch only)
     const int n_base = slot * 64, ncols = min(64, dim - n_base);
     const float* xr = x + (size_t)row * ldx;
     float v[4][4];
@@ -388,11 +389,11 @@ __global__ __launch_bounds__(256) void ivit_row_stats_pairs(const float* __restr
     if (fq == 0 && live && ncols > 0) part[(size_t)row * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
 }
 
-hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16) {
-    if (dim % 4 || dim > 64 * GEMM_LN_SLOTS) return hipErrorInvalidValue;
+hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16, int row_step) {
+    if (dim % 4 || dim > 64 * GEMM_LN_SLOTS || row_step < 1) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
     const int64_t threads = (int64_t)rows * ((dim + 63) >> 6) * 4;
-    hipLaunchKernelGGL(ivit_row_stats_pairs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, ldx, rows, dim, xb, ldxb, part, f16);
+    hipLaunchKernelGGL(ivit_row_stats_pairs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, ldx, rows, dim, xb, ldxb, part, f16, row_step);
     return hipGetLastError();
 }
 

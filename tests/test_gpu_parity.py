@@ -171,6 +171,30 @@ def test_stage_ranges_compose(small):
         assert torch.equal(b, full), f"cut at {cut}"
 
 
+def test_fused_range_takes_layer0_statistics_from_the_patch_gemm(small):
+    """A range that runs the patch embedding INTO an encoder layer lets the patch GEMM's epilogue (EPI_BIAS_ROWADD_STATS, the `_rs` kernel)
+    leave the LayerNorm statistics pairs and the 16-bit copy of the token rows; ivit_row_stats_pairs then visits the class rows only.  Same
+    bytes as the range cut in front of the layer, where the statistics kernel reads the whole token stream."""
+    cfg, sd, eng = small
+    if not eng.ln_fold_for(3):
+        pytest.skip("LayerNorm fold off")
+    x = synthetic_images(3, cfg, seed=41).cuda()
+
+    def profiled(fn):
+        eng.profile(True); eng.profile_reset()
+        out = fn()
+        kern = eng.profile_kernels(); eng.profile(False)
+        return out, kern
+
+    fused, kern = profiled(lambda: eng.forward(x, 0, 4))                  # transform .. encoder.layers.0
+    patch = [k for k in kern if k.startswith("patch:")]
+    assert len(patch) == 1 and patch[0].endswith("_rs"), sorted(kern)
+    assert sum(v["launches"] for k, v in kern.items() if k.startswith("layernorm")) == 1      # the class rows
+    tok, kern_t = profiled(lambda: eng.forward(x, 0, 3))                  # ends on the tokens: plain row-add epilogue
+    assert not [k for k in kern_t if k.startswith("patch:")][0].endswith("_rs"), sorted(kern_t)
+    assert torch.equal(eng.forward(tok, 3, 4), fused)
+
+
 def test_errors_are_exceptions_with_messages(small):
     from interactive_vit_amd.engine import EngineError
     cfg, sd, eng = small
