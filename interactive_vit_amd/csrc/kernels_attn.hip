@@ -155,6 +155,14 @@ __device__ __forceinline__ void att_block(const AttnParams& p, const char* k_lds
     f32x4 o[L::NDB];
 #pragma unroll
     for (int d = 0; d < L::NDB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // The transposed V reads of step st are at  vbase[d] + st * 32 rows  (+ 16 rows for the second half of the k-slots): the swizzle term
+    // ((key >> 1) & 3 of key = 32 st + 16 half + 4 g + tq) does not depend on st or the half, but the compiler cannot know 4 g + tq < 16 and
+    // kept one address register per (st, d, half) - 152 block-invariant registers at 577 keys, hoisted in front of the block loop, which
+    // spilled 52 dwords when the kernel was last recompiled (ViT-L/16-384 attention 340 -> 645 us per launch; round 3).  Written as base +
+    // constant the offsets are instruction immediates.
+    int vbase[L::NDB];
+#pragma unroll
+    for (int d = 0; d < L::NDB; ++d) vbase[d] = L::v_off(4 * g + tq, d * 2 + (tp >> 1)) + (tp & 1) * 8;
 #pragma unroll
     for (int st = 0; st < NKF / 2; ++st) {
         const f32x4 p0 = s[2 * st], p1 = s[2 * st + 1];
@@ -163,12 +171,10 @@ __device__ __forceinline__ void att_block(const AttnParams& p, const char* k_lds
         pk.u[1] = OP::pack2(p0[2], p0[3]);
         pk.u[2] = OP::pack2(p1[0], p1[1]);
         pk.u[3] = OP::pack2(p1[2], p1[3]);
-        const int key_lo = 32 * st + 4 * g + tq;       // first half of the k-slots; second half = +16 keys
 #pragma unroll
         for (int d = 0; d < L::NDB; ++d) {
-            const int chunk = d * 2 + (tp >> 1);       // 16-B chunk of columns d*16 + 4*tp
-            const char* lo = v_lds + L::v_off(key_lo, chunk) + (tp & 1) * 8;
-            const char* hi = v_lds + L::v_off(key_lo + 16, chunk) + (tp & 1) * 8;
+            const char* lo = v_lds + vbase[d] + st * 32 * L::ROW;   // keys 32 st + 4 g + tq: first half of the k-slots, 16-B chunk of columns d*16 + 4*tp
+            const char* hi = lo + 16 * L::ROW;                      // second half = + 16 keys
             union { bf16x8 v; bf16x4 h2[2]; } vf;
             vf.h2[0] = lds_read_tr16(lo);
             if (ODD && st == NKF / 2 - 1) vf.h2[1] = bf16x4{0, 0, 0, 0};   // the fragment that is not in LDS: its P is exactly 0
@@ -227,7 +233,12 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     const int q0 = wave * 16;
 
     // ---- K and V by LDS-DMA (row-major, 16-B chunks, swizzle applied on the source address)
+#ifdef IVIT_GEMM_ABLATIONS   // head-major q|k|v layouts of the study build (tools/fused_bench); run-time strides cost the 577-key instantiation its last registers
     const size_t hs = p.head_stride ? (size_t)p.head_stride : (size_t)ATT_DH, ws = p.which_stride ? (size_t)p.which_stride : (size_t)D;
+#else
+    constexpr int hs = ATT_DH;
+    const int ws = D;
+#endif
     att_stage<L>(k_lds, qkv + row0 * ld + h * hs + ws, ld, N, L::K_SWZ, wave, nwaves, lane);
     att_stage<L>(v_lds, qkv + row0 * ld + h * hs + 2 * ws, ld, N, L::V_SWZ, wave, nwaves, lane);
 
