@@ -53,7 +53,7 @@ struct GemmParams {
     int order;                      // microbenchmark builds only: 1 = row bands per XCD (tile_coords_banded), 2 = pairs sharing a CU (gemm_body)
 };
 
-enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_TILE_PE = 8, GEMM_TILE_64D = 9, GEMM_TILE_P160 = 10, GEMM_TILE_P128 = 11, GEMM_TILE_128W8A = 12, GEMM_TILE_128W8B = 13, GEMM_TILE_160W8 = 14, GEMM_TILE_128SB = 15, GEMM_TILE_160SB = 16, GEMM_VARIANTS = 17 };
+enum GemmVariant : int { GEMM_TILE_128 = 0, GEMM_TILE_160 = 1, GEMM_TILE_256 = 2, GEMM_TILE_256P = 3, GEMM_TILE_256S = 4, GEMM_TILE_256PS = 5, GEMM_TILE_160X256 = 6, GEMM_TILE_160X256W4 = 7, GEMM_TILE_PE = 8, GEMM_TILE_64D = 9, GEMM_TILE_P160 = 10, GEMM_TILE_P128 = 11, GEMM_TILE_128W8A = 12, GEMM_TILE_128W8B = 13, GEMM_TILE_160W8 = 14, GEMM_TILE_128SB = 15, GEMM_TILE_160SB = 16, GEMM_TILE_256X128SB = 17, GEMM_TILE_192SB = 18, GEMM_VARIANTS = 19 };
 // product variants: GEMM_TILE_128SB / 160SB (one operand stage, three workgroups per CU), GEMM_TILE_256S, GEMM_TILE_64D; the others exist only in
 // microbenchmark builds (IVIT_GEMM_ABLATIONS: two-stage tiles, persistent kernels, eight-wave forms - csrc/study/)
 // GEMM_TILE_P160 / P128 (study/gemmp_kernel.h: persistent two-per-CU workgroups, the finished tile's LayerNorm-fold epilogue drained inside

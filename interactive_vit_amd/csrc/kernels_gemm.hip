@@ -99,6 +99,21 @@ IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_lf, 2, OpF16)
 IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64, Tile128, 0, OpBf16)
 IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64_rs, Tile128, 1, OpBf16)
 IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64_lf, Tile128, 2, OpBf16)
+// round 3 (late): single-stage tiles with MORE rows per workgroup, two workgroups per CU - fewer operand bytes per FLOP on the CU's vector-memory
+// return path (45-52 B/clk/CU whatever the source: tools/dma_l1_probe): 256 x 128 on four waves of 128 x 64 (11.7 B/KFLOP against 14.1), 192 x 128 (13.0)
+using Tile256x128 = GemmTile<2, 2, 8, 4>;
+using Tile192 = GemmTile<2, 2, 6, 4>;
+#define IVIT_SB2_KERNEL(NAME, TILE, EK)                                                       \
+    __global__ __launch_bounds__(TILE::THREADS, 2) void NAME(GemmParams p) {                  \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
+        gemm_body_sb<TILE, false, EK, OpBf16>(p, smem);                                       \
+    }
+IVIT_SB2_KERNEL(ivit_gemm_bf16_256x128x64_sb, Tile256x128, 0)
+IVIT_SB2_KERNEL(ivit_gemm_bf16_256x128x64_sb_rs, Tile256x128, 1)
+IVIT_SB2_KERNEL(ivit_gemm_bf16_256x128x64_sb_lf, Tile256x128, 2)
+IVIT_SB2_KERNEL(ivit_gemm_bf16_192x128x64_sb, Tile192, 0)
+IVIT_SB2_KERNEL(ivit_gemm_bf16_192x128x64_sb_rs, Tile192, 1)
+IVIT_SB2_KERNEL(ivit_gemm_bf16_192x128x64_sb_lf, Tile192, 2)
 // persistent two-per-CU workgroups (study/gemmp_kernel.h; round 3): bit-identical, SLOWER (mlp1 + fold + GELU 92.8 us against 80.0; section
 // stamps: profiles/r03a_persist_sections.txt) - IVIT_PERSIST_DUAL 1 = the finished tile's epilogue drained inside the next tile's loop
 #ifndef IVIT_PERSIST_DUAL
@@ -191,6 +206,8 @@ const char* gemm_variant_name(int v) {
         case GEMM_TILE_160X256W4: return "ivit_gemm_bf16_160x256x64_w4";
         case GEMM_TILE_256PS: return "ivit_gemm_bf16_256x256x64_persist";
         case GEMM_TILE_PE: return "ivit_gemm_bf16_256x128x64_pe";
+        case GEMM_TILE_256X128SB: return "ivit_gemm_bf16_256x128x64_sb";
+        case GEMM_TILE_192SB: return "ivit_gemm_bf16_192x128x64_sb";
         case GEMM_TILE_64D: return "ivit_gemm_bf16_64x128x64_deep";
         case GEMM_TILE_P160: return "ivit_gemm_bf16_160x128x64_plf";
         case GEMM_TILE_P128: return "ivit_gemm_bf16_128x128x64_plf";
@@ -359,6 +376,10 @@ static hipError_t launch_study_variant(const GemmParams& p, int variant, int fam
         case GEMM_TILE_P128: return launch_persist_lf<Tile128>(p, stream);
         case GEMM_TILE_128:
             return family == 1 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_rs, p, stream) : family == 2 ? launch_tile<Tile128>(ivit_gemm_bf16_128x128x64_lf, p, stream, Tile128::BM * 8) : launch_tile<Tile128>(ivit_gemm_bf16_128x128x64, p, stream);
+        case GEMM_TILE_256X128SB:
+            return family == 1 ? launch_sb<Tile256x128>(ivit_gemm_bf16_256x128x64_sb_rs, p, stream) : family == 2 ? launch_sb<Tile256x128>(ivit_gemm_bf16_256x128x64_sb_lf, p, stream, Tile256x128::BM * 8) : launch_sb<Tile256x128>(ivit_gemm_bf16_256x128x64_sb, p, stream);
+        case GEMM_TILE_192SB:
+            return family == 1 ? launch_sb<Tile192>(ivit_gemm_bf16_192x128x64_sb_rs, p, stream) : family == 2 ? launch_sb<Tile192>(ivit_gemm_bf16_192x128x64_sb_lf, p, stream, Tile192::BM * 8) : launch_sb<Tile192>(ivit_gemm_bf16_192x128x64_sb, p, stream);
         case GEMM_TILE_128W8A:
             if (family == 1) return hipErrorInvalidValue;
             return family == 2 ? launch_tile<Tile128W8A>(ivit_gemm_bf16_128x128x64_w8a_lf, p, stream, Tile128W8A::BM * 8) : launch_tile<Tile128W8A>(ivit_gemm_bf16_128x128x64_w8a, p, stream);
