@@ -374,7 +374,10 @@ static hipError_t launch_nkf_op(const AttnParams& p, hipStream_t stream) {
         }
     }
 #endif
-    const int waves = std::min(8, blocks);
+    int waves = std::min(8, blocks);
+#ifdef IVIT_GEMM_ABLATIONS
+    { static const int w = [] { const char* v = getenv("IVIT_ATT_WAVES"); return v ? atoi(v) : 0; }(); if (w > 0) waves = std::min(w, blocks); }   // study knob
+#endif
     dim3 grid(1, p.heads, p.batch);
     hipLaunchKernelGGL((ivit_attention_bf16<DH, NKF, ODD, PROBS, OP>), grid, dim3(waves * 64), L::LDS_BYTES, stream, p);
     return hipGetLastError();
