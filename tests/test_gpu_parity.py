@@ -529,6 +529,12 @@ def test_head_dim_80_and_patch_14_small():
         strict_nodes(eng, cfg, sd, acts, x, vit_oracle.node_suffixes(cfg))
         logits = eng.forward(x.cuda(), 0, len(eng.stages))
         assert rel_err(logits, acts["logits"]) <= e2e_bound(cfg)
+        # the fused range (patch GEMM leaving layer 0's statistics: 5 slots of 64 columns, 17 tokens, K padded 588 -> 640) and the node
+        # chain (statistics kernel over the whole stream) give the same bits
+        cur = x.cuda()
+        for suffix in vit_oracle.node_suffixes(cfg):
+            cur = eng.run_node(suffix, cur)
+        assert torch.equal(cur.cpu(), logits.cpu())
         amap = eng.run_node("encoder.layers.1.attn", acts["encoder.layers.0"].cuda()).cpu()
         emu = vit_oracle.attention_map(acts["encoder.layers.0"].double(), sd, 1, cfg, emulate=True)
         assert rel_err(amap, emu) <= REL_TOL
