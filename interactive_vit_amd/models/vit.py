@@ -145,7 +145,8 @@ class HipBackend:
     """The product backend: owns an ``Engine`` on one GPU.  Raises if the GPU path is unavailable."""
 
     def __init__(self, cfg: VitConfig, state_dict: Dict[str, torch.Tensor], device: int = 0, max_batch: int = 1,
-                 precision: str = "bf16", check_ln_fold: bool = True):
+                 precision: str = "bf16", check_ln_fold: bool = True, calibration_images: Optional[torch.Tensor] = None,
+                 ln_fold_threshold: float = 0.5):
         from ..engine import Engine  # raises when libivit.so is missing
         from ..weights import synthetic_images
         if not torch.cuda.is_available():
@@ -156,9 +157,15 @@ class HipBackend:
         # A plugin takes whatever checkpoint it is given (reference static/models/vgg16.py:12-14).  The LayerNorm fold
         # of the engine is only as accurate as the unfolded form while |mean| / std of the residual-stream rows is
         # small, a property of the weights: measure it once on sample images and let the engine keep or drop the fold.
+        # `calibration_images` ([B,3,S,S] in [0,1], B <= max_batch): real sample pictures of the deployment when the operator has some
+        # (a real checkpoint's residual stream depends on its inputs); else two seeded synthetic images.  `ln_fold_threshold`: the
+        # largest |mean| / std the fold is kept for (engine default 0.5); the measured ratio is kept in `ln_fold_ratio`.
         self.ln_fold_ratio = None
         if check_ln_fold and precision != "fp8" and self.engine.ln_fold:
-            self.ln_fold_ratio = self.engine.calibrate_ln_fold(synthetic_images(min(2, max_batch), cfg, seed=7))
+            images = calibration_images if calibration_images is not None else synthetic_images(min(2, max_batch), cfg, seed=7)
+            if images.dim() == 3:
+                images = images.unsqueeze(0)
+            self.ln_fold_ratio = self.engine.calibrate_ln_fold(images[:max_batch], threshold=ln_fold_threshold)
 
     def module(self) -> torch.nn.Module:
         return self._module
@@ -169,7 +176,7 @@ class HipBackend:
 
 def build_plugins(ModelBase, PinoutCls, variants: Sequence[str] = ("vit_b_16",), device: int = 0,
                   max_batch: int = 1, seed: int = 0, state_dicts: Optional[Dict[str, Dict[str, torch.Tensor]]] = None,
-                  precision: str = "bf16"):
+                  precision: str = "bf16", calibration_images: Optional[torch.Tensor] = None, ln_fold_threshold: float = 0.5):
     """What a plugin file's ``instances()`` returns: one registered model per variant.
 
     Weights: ``state_dicts[name]`` when given (e.g. loaded from a local safetensors file with
@@ -180,7 +187,8 @@ def build_plugins(ModelBase, PinoutCls, variants: Sequence[str] = ("vit_b_16",),
     for v in variants:
         cfg = VARIANTS[v]
         sd = (state_dicts or {}).get(v) or init_weights(cfg, seed=seed, mode="spec")
-        models.append(cls(cfg, HipBackend(cfg, sd, device=device, max_batch=max_batch, precision=precision)))
+        models.append(cls(cfg, HipBackend(cfg, sd, device=device, max_batch=max_batch, precision=precision,
+                                          calibration_images=calibration_images, ln_fold_threshold=ln_fold_threshold)))
     return models
 
 

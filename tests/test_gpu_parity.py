@@ -880,3 +880,11 @@ def test_checkpoint_file_through_the_engine(tmp_path):
         assert torch.equal(a.run_node("forward", x), b.run_node("forward", x))
     finally:
         a.engine.close(); b.engine.close()
+    # the operator's own sample pictures and threshold decide the fold for that checkpoint: a threshold below the measured ratio drops it
+    c = HipBackend(cfg, loaded, device=0, max_batch=2, calibration_images=synthetic_images(2, cfg, seed=99), ln_fold_threshold=1e-6)
+    d = HipBackend(cfg, loaded, device=0, max_batch=2, calibration_images=synthetic_images(1, cfg, seed=99)[0], ln_fold_threshold=1e6)
+    try:
+        assert c.ln_fold_ratio > 1e-6 and not c.engine.ln_fold_for(2)
+        assert d.engine.ln_fold_for(2)
+    finally:
+        c.engine.close(); d.engine.close()
