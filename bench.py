@@ -26,7 +26,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) extended with
   "step_ms"      - median / p10 / p90 of per-step device time over >= 50 further steps;
   "pcie_inclusive" - images/s with the batch uploaded from pinned host memory and the logits
                    downloaded every step (never `value`);
-  "parity"       - max|gpu - ref| / max|ref| against the oracle in the same run, per node class.
+  "parity"       - max|gpu - ref| / max|ref| against the oracle in the same run, per node class;
+  "tolerance_mode" - (bf16 runs on one GPU) the same workload on IVIT_PRECISION_F16X, the precision that is inside
+                   north_star's 1e-3 of the CPU f32 forward: images/s, GEMM-class fraction, logits vs the plain f32 oracle.
 """
 from __future__ import annotations
 
@@ -61,7 +63,8 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=None)
     ap.add_argument("--precision", default=None, choices=["bf16", "f16", "f16x", "fp8"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-tolerance-mode", action="store_true", help="skip the f16x sub-record of a bf16 run")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline: total seconds over its three samples")
     args = ap.parse_args()
     model, batch, prec = CONFIGS[args.config or 2]
     args.model = args.model or model
@@ -78,6 +81,16 @@ def _cpu_threads() -> int:
     except AttributeError:
         avail = os.cpu_count() or 1
     return max(1, min(avail, int(os.environ.get("IVIT_CPU_THREADS", "16"))))
+
+
+def _cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def _cpu_chain(cfg, sd, batch, seconds, max_iters=200):
@@ -157,9 +170,13 @@ def cpu_baseline(cfg, sd, seconds: float):
     from interactive_vit_amd.weights import init_weights
     cores = _cpu_threads()
     torch.set_num_threads(cores)
-    v, iters, el = _cpu_chain(cfg, sd, 8, seconds)
+    # best of three samples (one 12 s sample read 25.8 / 24.0 / 16.9 img/s on three boxes - the first forwards of a
+    # process and whatever else the host runs are in a single sample); the CPU model and the thread count travel with the number
+    runs = [_cpu_chain(cfg, sd, 8, max(5.0, seconds / 3.0)) for _ in range(3)]
+    v, iters, el = max(runs, key=lambda r: r[0])
     res = {"value": v, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{cfg.name} batch 8 x {iters} forwards, node by node through Context.compute, f32, {el:.1f} s"}
+           "sample": f"{cfg.name} batch 8 x {iters} forwards, node by node through Context.compute, f32, best of 3 samples of {el:.1f} s "
+                     f"({', '.join(f'{r[0]:.1f}' for r in runs)} img/s) on {torch.get_num_threads()} threads of {_cpu_model()}"}
     # ViT-B/16 at B = 1 and 16, and ViT-Ti/16 B = 1 through the byte path (BASELINE config 1); bounded samples
     extra = {}
     try:
@@ -176,6 +193,51 @@ def cpu_baseline(cfg, sd, seconds: float):
         extra["error"] = repr(ex)
     res["extra"] = extra
     return res
+
+
+def tolerance_mode_record(cfg, sd, x, B, steps, warmup, dev, local_rank, precision="f16x"):
+    """The same workload on the precision that meets north_star's 1e-3 against the CPU f32 node-graph forward
+    (include/ivit.h: IVIT_PRECISION_F16X - f16 operands, MLP weights as hi + lo pairs), measured in the same run beside
+    the bf16 headline: images/s, ms per step, GEMM-class roofline fraction and the logits' distance from the PLAIN f32
+    oracle (what the reference's sub(x) returns, main/context.py:79-88)."""
+    from interactive_vit_amd.engine import Engine
+    from oracle import vit_oracle as vo
+    eng = Engine(cfg, sd, device=local_rank, max_batch=B, precision=precision)
+    try:
+        ns = len(eng.stages)
+        stream = torch.cuda.current_stream(dev)
+        logits = torch.empty((B, cfg.classes), dtype=torch.float32, device=dev)
+        clsf = torch.empty((B, cfg.dim), dtype=torch.float32, device=dev)
+        for _ in range(warmup):
+            eng.forward_into(x, logits, clsf, B, 0, ns, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.forward_into(x, logits, clsf, B, 0, ns, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        eng.profile(True)
+        eng.profile_reset()
+        for _ in range(steps):
+            eng.forward_into(x, logits, clsf, B, 0, ns, stream.cuda_stream)
+        g = eng.profile_read()["gemm"]
+        kern = eng.profile_kernels()
+        eng.profile(False)
+        tf = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        nimg = min(4, B)
+        xs = x[:nimg].cpu()
+        ref = vo.forward(xs, sd, cfg)["logits"].double()
+        got = logits[:nimg].cpu().double()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        return {"precision": precision, "split_gemms": sorted(eng.split_gemms), "value": round(B * steps / el, 1), "unit": "images/s",
+                "ms_per_step": round(el * 1e3 / steps, 4), "steps": steps,
+                "gemm_useful_tflops": round(tf, 1), "gemm_frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4),
+                "gemm_kernels": sorted({k.split(":", 1)[1] for k in kern if k.split(":", 1)[1].startswith("ivit_gemm")}),
+                "logits_vs_plain_f32_oracle": err, "images": nimg, "bound": 1e-3, "ok": bool(err <= 1e-3),
+                "what": "f16 MFMA operands (the bf16 rate on gfx950); MLP up / down weights as hi + lo pairs of f16 values (two passes, one f32 "
+                        "accumulator), patch embedding and head on pairs of both operands; useful FLOPs only in the TFLOP/s figure"}
+    finally:
+        eng.close()
 
 
 def device_info(dev):
@@ -301,16 +363,18 @@ def main():
     step_no = [0]
 
     def step():
-        eng.forward_into(x, logits, clsf, B, 0, ns, stream.cuda_stream)
-        if use_dist:
+        if not use_dist:
+            eng.forward_into(x, logits, clsf, B, 0, ns, stream.cuda_stream)
+        else:
             k = step_no[0] & 1
             step_no[0] += 1
             if pending[k] is not None:
                 pending[k].wait()                               # the collective that last used this buffer pair
-            packed[k][:, :cfg.classes].copy_(logits)
-            packed[k][:, cfg.classes:].copy_(clsf)
+            # the head GEMM and the final LayerNorm write [logits | class features] straight into the packed block (row stride
+            # classes + D): a step is the forward plus ONE ncclAllGather, no torch kernels in between
+            eng.forward_packed(x, packed[k], B, 0, stream.cuda_stream)
             if engine_gather:
-                eng.allgather(packed[k], gathered[k], stream.cuda_stream)                             # the ONE collective of the path
+                eng.allgather_rows(packed[k], total, gathered[k], stream.cuda_stream)                 # the ONE collective of the path
             elif overlap:
                 pending[k] = all_gather_outputs(packed[k], total, out=gathered[k], async_op=True)   # the ONE collective of the path
             else:
@@ -456,7 +520,11 @@ def main():
         # chain; f16 / bf16 / fp8 are bounded at their measured operand-rounding distance + 25 % (8 significant
         # bits cannot be inside 1e-3 of f32).  Against the rounding-aware oracle (the same rounding points): 1e-3 per node.
         e2e_bound = {"f16x": 1e-3, "f16": 1.3e-3, "bf16": 1.2e-2, "fp8": 1.5e-1}[args.precision]
+        # per node vs the rounding-aware oracle: 1e-3.  ViT-H/14's layers measure 8.6e-4 on the 2 bench images (profiles/r03b_bench_h14_bf16.json)
+        # and 1.02e-3 ... 1.13e-3 at B = 256 in tests/test_gpu_configs.py (five chained roundings at K = 1280 / 5120 decorrelate two correct
+        # evaluations): its bound is that measurement + 15 %, not a free allowance
         node_bound = 1.3e-3 if cfg.name == "vit_h_14" else 1e-3
+        fp8_vs_fp8_oracle_bound = 9.0e-2   # measured 7.1e-2 on ViT-H/14 (profiles/r03b_bench_c5.json) + 25 %: a wrong scale or a 10 % regression fails it
         eng.forward_into(x, logits, clsf, B, 0, ns, stream.cuda_stream)
         torch.cuda.synchronize(dev)
         xs = x[:2].cpu()
@@ -471,7 +539,8 @@ def main():
             emu = vo.forward_fp8(xs.double(), sd, cfg, eng.fp8_scales())["logits"]
             parity = {"logits_vs_fp8_oracle": rel(got, emu), "logits_vs_plain_f32_oracle": rel(got, ref),
                       "tolerance_per_gemm_fp8_same_inputs": 1e-3, "bound_logits_vs_plain_f32": e2e_bound, "images": 2}
-            parity["ok"] = bool(parity["logits_vs_plain_f32_oracle"] <= e2e_bound)
+            parity["bound_logits_vs_fp8_oracle"] = fp8_vs_fp8_oracle_bound
+            parity["ok"] = bool(parity["logits_vs_plain_f32_oracle"] <= e2e_bound and parity["logits_vs_fp8_oracle"] <= fp8_vs_fp8_oracle_bound)
         else:
             emu = vo.forward(xs.double(), sd, cfg, emulate=True)["logits"]
             parity = {f"logits_vs_{args.precision}_rounding_oracle": rel(got, emu), "logits_vs_plain_f32_oracle": rel(got, ref),
@@ -496,6 +565,15 @@ def main():
                                                    and torch.equal(last[b0:b1, cfg.classes:], clsf))
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, sd, args.cpu_seconds)
+    # ---- the tolerance mode beside the headline (one GPU, bf16 headline runs only): a rate that IS inside north_star's 1e-3
+    tolerance = None
+    folded = args.precision != "fp8" and eng.ln_fold_for(B)
+    if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_tolerance_mode:
+        eng.close()   # its workspaces are not needed any more; the second engine is measured alone on the device
+        try:
+            tolerance = tolerance_mode_record(cfg, sd, x, B, args.steps, args.warmup, dev, local_rank)
+        except Exception as ex:   # never takes the headline down; the record says what happened
+            tolerance = {"precision": "f16x", "error": repr(ex), "ok": False}
 
     if use_dist:
         dist.barrier()
@@ -509,14 +587,14 @@ def main():
                                    "f32 images resident in HBM -> f32 logits + class-token features"
                                    + (", one RCCL all-gather per step" if use_dist else ""),
                        "baseline_config": args.config or (2 if (args.model, B, args.precision) == CONFIGS[2] else None),
-                       "collective": ("ncclAllGather issued by the engine (ivit_allgather_cls, RCCL), 1 per step" if engine_gather
+                       "collective": ("ncclAllGather issued by the engine (ivit_allgather_rows, RCCL) on the packed block the forward wrote in place, 1 per step" if engine_gather
                                       else "all_gather_into_tensor over nccl (RCCL), 1 per step") if use_dist else None,
                        "collective_overlap": ("async on RCCL's stream behind the next step's compute, drained inside the timed region" if overlap else "in line") if use_dist else None,
                        "batch_per_gpu": B, "global_batch": total, "tokens": cfg.tokens,
                        "gflop_per_image": round(flops_img / 1e9, 3), "parallelism": f"dp{world}",
                        "weights": "random init N(0,0.02^2) seed 0",
-                       "layernorm": "folded into the consuming GEMMs" if (args.precision != "fp8" and eng.ln_fold_for(B)) else "kernel"},
-            "roofline": roofline, "cpu_baseline": cpu, "step_ms": step_ms, "pcie_inclusive": pcie, "parity": parity,
+                       "layernorm": "folded into the consuming GEMMs" if folded else "kernel"},
+            "roofline": roofline, "cpu_baseline": cpu, "tolerance_mode": tolerance, "step_ms": step_ms, "pcie_inclusive": pcie, "parity": parity,
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
@@ -524,6 +602,9 @@ def main():
     if use_dist:
         dist.barrier()     # rank 0's parity / instrumented pass runs after the timed loop: leave together
         dist.destroy_process_group()
+    if rank == 0 and tolerance is not None and not tolerance.get("ok", True):
+        print(f"bench.py: TOLERANCE MODE outside 1e-3 (the result line was printed; see its 'tolerance_mode' object): {json.dumps(tolerance)}", file=sys.stderr)
+        sys.exit(3)
     if rank == 0 and parity is not None and not parity.get("ok", True):
         print(f"bench.py: PARITY BOUND VIOLATED (the result line was printed; see its 'parity' object): {json.dumps(parity)}", file=sys.stderr)
         sys.exit(3)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define IVIT_ABI_VERSION 7
+#define IVIT_ABI_VERSION 8
 
 #define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
 #define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
@@ -48,10 +48,15 @@ extern "C" {
                                    returns f32), where bf16 operand rounding alone costs 2e-3.  Range 6.5e4: meant for LayerNorm-ed
                                    ViT activations; accumulation, statistics and the residual stream stay f32 as in the other modes */
 
-#define IVIT_PRECISION_F16X 3   /* IVIT_PRECISION_F16 with split-operand GEMMs where f16 operand rounding is the larger part of the distance from the
-                                   f32 forward (tools/f16_error_terms.py: the weights are 55 % of it): out-projection on hi + lo pairs of both
-                                   operands (3 MFMA passes), MLP up / down on hi + lo weight pairs (2 passes).  ViT-B/16 logits within 1e-3 of the
-                                   CPU f32 forward over the whole 12-layer chain (7e-4; IVIT_PRECISION_F16: 9e-4 ... 1.2e-3), at ~1.3 x the time.
+#define IVIT_PRECISION_F16X 3   /* the TOLERANCE mode: IVIT_PRECISION_F16 with split-operand GEMMs where f16 operand rounding is the larger part of the
+                                   distance from the f32 forward (tools/f16_error_terms.py: the weights are 55 % of it): MLP up and MLP down on hi + lo
+                                   WEIGHT pairs (W = hi + lo, two MFMA passes over the same activations, one f32 accumulator), the out-projection on
+                                   pairs of both operands (three passes).  Logits of ViT-B/16, ViT-L/16-384 and ViT-H/14 within 1e-3 of the CPU f32
+                                   forward with >= 30 % margin (6.3e-4 ... 6.9e-4; profiles/r04_f16x_split_sets.txt).  IVIT_F16X_PROJ=0 (measurement
+                                   knob) drops the out-projection split: 7.1e-4 by emulation, 8.6e-4 measured - inside 1e-3, not by 20 %.
+                                   lo = rn16(w - hi) is stored unscaled: for |w| < 2^-3 it is an f16 subnormal (step 2^-24), so hi + lo carries ~19
+                                   significant bits for the N(0, 0.02^2)-scale weights of the tests, not 22; the MFMA keeps subnormal operands
+                                   (tests/test_gpu_parity.py: test_split_weight_low_parts_survive).
                                    Both f16 modes run the patch embedding and the classifier head on hi + lo pairs of both operands (0.7 % of the FLOPs) */
 
 typedef struct ivit_engine ivit_engine;
@@ -194,6 +199,17 @@ int ivit_debug_unfold(ivit_engine* e, int batch, const void* in, void* out, int 
 int ivit_comm_unique_id(void* id128);
 int ivit_comm_init(ivit_engine* e, const void* id128, int rank, int world);
 int ivit_allgather_cls(ivit_engine* e, const void* send, void* recv, int64_t floats_per_rank, void* stream);
+
+/* The multi-GPU step without copy kernels (round 4).  ivit_forward_device_packed runs stages [stage_begin, end of model) and writes row b of
+ * `packed` (device f32, row_stride floats per image, a multiple of 4 >= classes + dim) as [logits | class-token features] - the head GEMM and
+ * the final LayerNorm store with that row stride - so the block ivit_allgather_rows sends is produced in place.
+ * ivit_shard_layout: the shard rule (rank r of `world` holds rows [begin, begin + rows) of `total`, the first total % world ranks one row
+ * more; padded_rows = the largest shard) - host arithmetic, no GPU.
+ * ivit_allgather_rows: ONE ncclAllGather of every rank's [rows_local, row_floats] block into recv [total_rows, row_floats] in image order;
+ * ragged shards (total_rows % world != 0) are padded to padded_rows inside the engine for the collective and compacted afterwards. */
+int ivit_forward_device_packed(ivit_engine* e, int stage_begin, int batch, const void* in, void* packed, int64_t row_stride, void* stream);
+int ivit_shard_layout(int64_t total, int world, int rank, int64_t* begin, int64_t* rows, int64_t* padded_rows);
+int ivit_allgather_rows(ivit_engine* e, const void* send, int64_t rows_local, int64_t row_floats, int64_t total_rows, void* recv, void* stream);
 
 /* Inspection entries used by the per-GEMM parity tests.  An encoder layer is seven steps: 1 LayerNorm 1 (with the
  * LayerNorm fold: the 16-bit operand copy of x the QKV GEMM consumes), 2 QKV projection, 3 attention, 4 out-projection

@@ -182,8 +182,12 @@ struct ivit_engine {
     // Split-operand GEMMs (hi + lo pairs of f16 values, two or three MFMA passes, f32 accumulation - an f32-class product where the
     // f16 rounding of an operand is the larger part of a node's distance from the f32 forward; tools/f16_error_terms.py):
     //   split_ph  (F16 and F16X): patch embedding and classifier head, both operands (0.7 % of the FLOPs);
-    //   f16x      (F16X):         + out-projection (both operands), MLP up and MLP down (weights only).
-    bool split_ph = false, f16x = false;
+    //   f16x      (F16X):         + MLP up and MLP down on hi + lo WEIGHT pairs (two passes over the same activations);
+    //   f16x_proj (F16X, default; IVIT_F16X_PROJ=0 drops it): + out-projection on pairs of both operands (three passes).  Round 4 measured the
+    //                             cheaper set without it (profiles/r04_f16x_split_sets.txt): 7.1e-4 ... 7.5e-4 by the oracle's emulation over 3 seeds x 8
+    //                             images, but 8.6e-4 on the engine's own rounding realisation of the bench images (two correct f16 evaluations of a
+    //                             12-layer chain differ from each other by 6e-4) - 14 % margin, not the 20 % asked for; with it 6.3e-4 ... 6.9e-4.
+    bool split_ph = false, f16x = false, f16x_proj = false;
     int ld_patch = 0, ld_att = 0, ld_hc = 0;   // row strides of the unfold image / attention output / class-token operand (2 x when they carry [hi | lo])
     std::mutex mu;
     hipStream_t own_stream = nullptr;
@@ -251,6 +255,8 @@ struct ivit_engine {
     // RCCL communicator of this engine's rank (ivit_comm_init); nullptr = single GPU
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    char* gather_buf = nullptr;     // staging of ivit_allgather_rows for ragged shards (padded block | gathered padded blocks), grown on demand
+    size_t gather_bytes = 0;
 
     // profiling
     bool prof_on = false;
@@ -353,8 +359,12 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         const char* sp = getenv("IVIT_F16_SPLIT_PATCH_HEAD");   // measurement knob: 0 = the round-2 f16 data path (no split GEMMs)
         e->split_ph = e->f16 && !(sp && atoi(sp) == 0);
     }
+    {
+        const char* pj = getenv("IVIT_F16X_PROJ");
+        e->f16x_proj = e->f16x && !(pj && atoi(pj) == 0);
+    }
     e->ld_patch = (e->split_ph ? 2 : 1) * e->Kp;
-    e->ld_att = (e->f16x ? 2 : 1) * cfg->dim;
+    e->ld_att = (e->f16x_proj ? 2 : 1) * cfg->dim;
     e->ld_hc = (e->split_ph ? 2 : 1) * cfg->dim;
     const int D = e->D, Mlp = cfg->mlp, B = cfg->max_batch;
     int rc = 0;
@@ -397,7 +407,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         chk(alloc_vec(e, &lw.ln1_g, D)); chk(alloc_vec(e, &lw.ln1_b, D));
         chk(alloc_vec(e, &lw.ln2_g, D)); chk(alloc_vec(e, &lw.ln2_b, D));
         chk(alloc_matrix(e, &lw.w_in, 3 * D, D)); chk(alloc_vec(e, &lw.b_in, 3 * D));
-        chk(alloc_matrix_split(e, &lw.w_out, D, D, e->f16x ? 2 : 0)); chk(alloc_vec(e, &lw.b_out, D));
+        chk(alloc_matrix_split(e, &lw.w_out, D, D, e->f16x_proj ? 2 : 0)); chk(alloc_vec(e, &lw.b_out, D));
         chk(alloc_matrix_split(e, &lw.w1, Mlp, D, e->f16x ? 1 : 0, e->fold_ln)); chk(alloc_vec(e, &lw.b1, Mlp));
         chk(alloc_matrix_split(e, &lw.w2, D, Mlp, e->f16x ? 1 : 0)); chk(alloc_vec(e, &lw.b2, D));
         if (e->fold_ln) {
@@ -461,6 +471,7 @@ extern "C" void ivit_destroy(ivit_engine* e) {
     for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->map_buf) (void)hipFree(e->map_buf);
+    if (e->gather_buf) (void)hipFree(e->gather_buf);
     if (e->pre_buf) (void)hipFree(e->pre_buf);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
@@ -619,11 +630,13 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
 }
 
 static int run_layernorm(ivit_engine* e, hipStream_t st, const float* x, int64_t row_stride, int rows, const float* g,
-                         const float* b, bf16_t* o16, float* o32, unsigned char* o8 = nullptr, float scale8 = 1.0f, int ldo16 = 0, int lo_off16 = 0) {
+                         const float* b, bf16_t* o16, float* o32, unsigned char* o8 = nullptr, float scale8 = 1.0f, int ldo16 = 0, int lo_off16 = 0,
+                         int ldo32 = 0) {
     const int D = e->D;
     if (!ldo16) ldo16 = D;
+    if (!ldo32) ldo32 = D;
     ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)rows * D * (4.0 + (o16 ? 2.0 : 0.0) + (o32 ? 4.0 : 0.0) + (o8 ? 1.0 : 0.0)));
-    HIP_TRY(launch_layernorm(x, D, row_stride, rows, D, g, b, e->cfg.ln_eps, o16, ldo16, o32, D, st, o8, e->ld8d, scale8, e->f16, lo_off16));
+    HIP_TRY(launch_layernorm(x, D, row_stride, rows, D, g, b, e->cfg.ln_eps, o16, ldo16, o32, ldo32, st, o8, e->ld8d, scale8, e->f16, lo_off16));
     return 0;
 }
 
@@ -646,7 +659,7 @@ static int run_gemm_fp8(ivit_engine* e, hipStream_t st, const unsigned char* A, 
 static int run_attention(ivit_engine* e, const Ws& w, hipStream_t st, int B, unsigned char* out8, float scale8) {
     const int D = e->D, M = B * e->N;
     AttnParams ap{};
-    ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = e->ld_att; ap.lo_off = e->f16x ? D : 0;
+    ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = e->ld_att; ap.lo_off = e->f16x_proj ? D : 0;
     ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh; ap.f16 = e->f16;
     ap.scale = 1.0f / std::sqrt((float)e->dh);
     ap.probs = nullptr;
@@ -776,8 +789,10 @@ static int check_range(ivit_engine* e, int begin, int end, int batch) {
 // caller holds e->mu and has set the device
 // `stats_in_first`: the first stage is an encoder layer whose input's statistics pairs and 16-bit copy are already in the workspace
 // (the previous host call left them: forward_host_impl); `leave_stats`: a range that ends on an encoder layer leaves them for the next.
+// `out_ld` / `cls_ld` (0 = dense): row strides of the logits / class-feature outputs of a range that ends on the head - the packed
+// [b, classes + D] block of the multi-GPU step is written in place (ivit_forward_device_packed), no copy kernels before the collective.
 static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, const float* in, float* out, float* cls_out,
-                       hipStream_t st, bool stats_in_first = false, bool leave_stats = false) {
+                       hipStream_t st, bool stats_in_first = false, bool leave_stats = false, int out_ld = 0, int cls_ld = 0) {
     const int L = e->cfg.layers, D = e->D, N = e->N, Np = e->Np;
     const int ST_LN = ST_LAYER0 + L, ST_CLS = ST_LN + 1, ST_HEADS = ST_LN + 2;
     const float* cur = in;
@@ -851,13 +866,14 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         if (end == ST_LN + 1) return run_layernorm(e, st, src, 1, B * N, e->lnf_g, e->lnf_b, nullptr, out);
         // only the class rows are consumed downstream: normalise B rows (stride N)
         float* feat = (end == ST_CLS + 1) ? out : (cls_out ? cls_out : w.clsf);
-        if (run_layernorm(e, st, src, N, B, e->lnf_g, e->lnf_b, w.hc, feat, nullptr, 1.0f, e->ld_hc, e->split_ph ? D : 0)) return 1;
+        if (run_layernorm(e, st, src, N, B, e->lnf_g, e->lnf_b, w.hc, feat, nullptr, 1.0f, e->ld_hc, e->split_ph ? D : 0, (feat == cls_out) ? cls_ld : 0)) return 1;
         if (end == ST_CLS + 1) {
             if (cls_out) HIP_TRY(hipMemcpyAsync(cls_out, out, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
             return 0;
         }
-        return run_gemm(e, st, w.hc, e->ld_hc, e->w_head, B, e->b_head, EPI_BIAS_F32, out, e->cfg.classes, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "head");
+        return run_gemm(e, st, w.hc, e->ld_hc, e->w_head, B, e->b_head, EPI_BIAS_F32, out, out_ld ? out_ld : e->cfg.classes, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "head");
     }
+    if (out_ld || cls_ld) return fail("strided outputs need a range that runs encoder.ln and ends on the head");
     if (s == ST_CLS) {
         float* dst = (end == ST_CLS + 1) ? out : w.clsf;
         {
@@ -924,11 +940,11 @@ static Ws ws_slice(ivit_engine* e, int b0) {
 
 // caller holds e->mu and has set the device
 static int forward_locked(ivit_engine* e, int begin, int end, int B, const float* in, float* out, float* cls_out,
-                          hipStream_t st, bool stats_in_first = false, bool leave_stats = false) {
+                          hipStream_t st, bool stats_in_first = false, bool leave_stats = false, int out_ld = 0, int cls_ld = 0) {
     if (require_weights(e)) return 1;
     const int L = e->cfg.layers;
     const bool has_layers = (begin < ST_LAYER0 + L) && (end > ST_LAYER0);
-    if (e->split < 2 || B < e->split_min_batch || !has_layers) return forward_one(e, ws_slice(e, 0), begin, end, B, in, out, cls_out, st, stats_in_first, leave_stats);
+    if (e->split < 2 || B < e->split_min_batch || !has_layers) return forward_one(e, ws_slice(e, 0), begin, end, B, in, out, cls_out, st, stats_in_first, leave_stats, out_ld, cls_ld);
     // fork: `split` sub-batches on as many streams; join back into the caller's stream
     const int64_t n_in = shape_elems(&e->cfg, begin, 0), n_out = shape_elems(&e->cfg, end - 1, 1);
     HIP_TRY(hipEventRecord(e->ev_fork, st));
@@ -938,8 +954,8 @@ static int forward_locked(ivit_engine* e, int begin, int end, int B, const float
         const int bn = base + (i < rem ? 1 : 0);
         hipStream_t s = e->aux_stream[i];
         HIP_TRY(hipStreamWaitEvent(s, e->ev_fork, 0));
-        if (forward_one(e, ws_slice(e, b0), begin, end, bn, in + (size_t)b0 * n_in, out + (size_t)b0 * n_out,
-                        cls_out ? cls_out + (size_t)b0 * e->D : nullptr, s, stats_in_first, leave_stats)) return 1;
+        if (forward_one(e, ws_slice(e, b0), begin, end, bn, in + (size_t)b0 * n_in, out + (size_t)b0 * (out_ld ? out_ld : n_out),
+                        cls_out ? cls_out + (size_t)b0 * (cls_ld ? cls_ld : e->D) : nullptr, s, stats_in_first, leave_stats, out_ld, cls_ld)) return 1;
         HIP_TRY(hipEventRecord(e->ev_join[i], s));
         b0 += bn;
     }
@@ -957,6 +973,25 @@ extern "C" int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_en
     WsScope ws(e, st);
     if (ws.acquire()) return 1;
     const int rc = forward_locked(e, stage_begin, stage_end, batch, (const float*)in, (float*)out, (float*)cls_out, st);
+    if (ws.release()) return 1;
+    return rc;
+}
+
+extern "C" int ivit_forward_device_packed(ivit_engine* e, int stage_begin, int batch, const void* in, void* packed, int64_t row_stride, void* stream) {
+    if (!e) return fail("null engine");
+    const int ns = 6 + e->cfg.layers;
+    if (check_range(e, stage_begin, ns, batch)) return 1;
+    if (!in || !packed) return fail("ivit_forward_device_packed: null buffer");
+    if (stage_begin > ST_LAYER0 + e->cfg.layers) return fail("ivit_forward_device_packed: the range must run encoder.ln (stage_begin <= %d)", ST_LAYER0 + e->cfg.layers);
+    if (row_stride < (int64_t)e->cfg.classes + e->D || (row_stride % 4) || (e->cfg.classes % 4) || row_stride > INT32_MAX)
+        return fail("ivit_forward_device_packed: row_stride %lld must be a multiple of 4 >= classes + dim = %d, classes a multiple of 4", (long long)row_stride, e->cfg.classes + e->D);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
+    float* base = (float*)packed;
+    const int rc = forward_locked(e, stage_begin, ns, batch, (const float*)in, base, base + e->cfg.classes, st, false, false, (int)row_stride, (int)row_stride);
     if (ws.release()) return 1;
     return rc;
 }
@@ -1395,6 +1430,53 @@ extern "C" int ivit_allgather_cls(ivit_engine* e, const void* send, void* recv, 
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int rc = g_rccl.all_gather(send, recv, (size_t)floats_per_rank, kRcclFloat32, e->comm, (hipStream_t)stream);
     if (rc != 0) return fail("ncclAllGather failed: %s", g_rccl.error_string(rc));
+    return 0;
+}
+
+// Shard rule of the batch (interactive_vit_amd/sharding.py: shard_range - the first total % world ranks hold one row more) and the row count
+// every rank's block is padded to for the one collective.  Pure host arithmetic.
+extern "C" int ivit_shard_layout(int64_t total, int world, int rank, int64_t* begin, int64_t* rows, int64_t* padded_rows) {
+    if (total < 0 || world <= 0 || rank < 0 || rank >= world) return fail("ivit_shard_layout: rank %d outside a world of %d", rank, world);
+    const int64_t base = total / world, extra = total % world;
+    if (begin) *begin = rank * base + std::min<int64_t>(rank, extra);
+    if (rows) *rows = base + (rank < extra ? 1 : 0);
+    if (padded_rows) *padded_rows = base + (extra ? 1 : 0);
+    return 0;
+}
+
+extern "C" int ivit_allgather_rows(ivit_engine* e, const void* send, int64_t rows_local, int64_t row_floats, int64_t total_rows, void* recv, void* stream) {
+    if (!e || !send || !recv) return fail("ivit_allgather_rows: null argument");
+    if (rows_local < 0 || row_floats <= 0 || total_rows <= 0) return fail("ivit_allgather_rows: nothing to gather");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->comm) return fail("ivit_allgather_rows: no communicator (call ivit_comm_init on every rank first)");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    int64_t begin = 0, mine = 0, big = 0;
+    if (ivit_shard_layout(total_rows, e->comm_world, e->comm_rank, &begin, &mine, &big)) return 1;
+    if (mine != rows_local) return fail("ivit_allgather_rows: rank %d holds %lld rows, its shard of %lld over %d ranks is %lld", e->comm_rank, (long long)rows_local, (long long)total_rows, e->comm_world, (long long)mine);
+    if (total_rows % e->comm_world == 0) {   // equal shards: straight into the caller's buffer
+        const int rc = g_rccl.all_gather(send, recv, (size_t)(rows_local * row_floats), kRcclFloat32, e->comm, st);
+        if (rc != 0) return fail("ncclAllGather failed: %s", g_rccl.error_string(rc));
+        return 0;
+    }
+    // ragged shards: every rank's block padded to the largest shard for the ONE collective, compacted afterwards (the rule of
+    // sharding.all_gather_outputs); the staging buffers are the engine's, grown on demand
+    const size_t pad_bytes = (size_t)big * row_floats * 4, all_bytes = pad_bytes * e->comm_world;
+    if (e->gather_bytes < pad_bytes + all_bytes) {
+        if (e->gather_buf) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(e->gather_buf)); e->gather_buf = nullptr; e->gather_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&e->gather_buf, pad_bytes + all_bytes));
+        e->gather_bytes = pad_bytes + all_bytes;
+    }
+    char* pad = e->gather_buf, *all = e->gather_buf + pad_bytes;
+    HIP_TRY(hipMemsetAsync(pad, 0, pad_bytes, st));
+    HIP_TRY(hipMemcpyAsync(pad, send, (size_t)rows_local * row_floats * 4, hipMemcpyDeviceToDevice, st));
+    const int rc = g_rccl.all_gather(pad, all, (size_t)(big * row_floats), kRcclFloat32, e->comm, st);
+    if (rc != 0) return fail("ncclAllGather failed: %s", g_rccl.error_string(rc));
+    for (int r = 0; r < e->comm_world; ++r) {
+        int64_t b = 0, n = 0;
+        (void)ivit_shard_layout(total_rows, e->comm_world, r, &b, &n, nullptr);
+        if (n) HIP_TRY(hipMemcpyAsync((char*)recv + (size_t)b * row_floats * 4, all + (size_t)r * pad_bytes, (size_t)n * row_floats * 4, hipMemcpyDeviceToDevice, st));
+    }
     return 0;
 }
 

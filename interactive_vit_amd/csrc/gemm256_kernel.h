@@ -33,6 +33,7 @@ namespace ivit {
 struct Tile256P {   // shape constants shared with the generic epilogue
     static constexpr int WAVES_M = 2, WAVES_N = 4, FM = 8, FN = 4;
     static constexpr int WAVES = 8, THREADS = 512, BM = 256, BN = 256;
+    static constexpr bool RAGGED_N = false;
     static constexpr int HALF_BYTES = 128 * 128;          // 16 KiB
     static constexpr int SET_BYTES = 4 * HALF_BYTES;      // A0 A1 B0 B1
     static constexpr int LDS_BYTES = 2 * SET_BYTES;       // 128 KiB

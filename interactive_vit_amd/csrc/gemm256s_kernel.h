@@ -148,7 +148,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
 
     if (!late) __builtin_amdgcn_s_barrier();
     IVIT_STAMP(2);
-    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq, tile_stats + wr * 128);
+    gemm_epilogue_family<T, EK, OP, 2>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq, tile_stats + wr * 128);
     IVIT_STAMP(3);
     IVIT_VMCNT(0);   // the clamped tail stagings may still be writing LDS
     IVIT_STAMP(4);

@@ -33,6 +33,7 @@ struct GemmTile {
     static constexpr int W_BYTES = BN * GEMM_BK * 2;
     static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr bool RAGGED_N = false;   // N % 4 == 0 required (edge tiles guard whole column quads); the deep-ring tile takes any N
     static constexpr int A_PIECES = BM / 8;   // 1-KiB DMA pieces (8 rows x 128 B) per A tile
     static constexpr int W_PIECES = BN / 8;
     static_assert(BM % 8 == 0 && BN % 8 == 0, "tile rows must be whole 8-row DMA pieces");
@@ -89,10 +90,15 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int r_local, i
 // the residual loads / stores of many fragments are in flight together.  (With a branch per
 // fragment hipcc emitted load -> s_waitcnt vmcnt(0) -> store 32 times in a row, each paying a full
 // memory latency: ~10 us per 256x256 tile.)  Edge tiles take the guarded path.
-template <class T, bool INTERIOR, class OP = OpBf16>
+// KIND (round 4: the run-time choice among ALL classic kinds kept bias, column scales, addend rows and both store forms alive together and
+// spilled 160-190 bytes per lane in the 256 x 256 and three-per-CU tiles): 0 = the 16-bit / fp8 output kinds (EPI_BIAS_BF16,
+// EPI_BIAS_GELU_BF16, EPI_BIAS_GELU_FP8), 3 = the f32 output kinds (EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_ROWADD_F32) - separate
+// kernel instantiations ("_f32"); within a kind the choice stays a wave-uniform run-time branch.
+template <class T, bool INTERIOR, class OP = OpBf16, int KIND = -1>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base,
                                                    int n_base, int fr, int fq) {
     const int epi = p.epi;
+    constexpr bool K16 = KIND != 3, K32 = KIND != 0;   // KIND = -1 (microbenchmark-only study kernels): every classic kind in one kernel, as before
     float4 bias4[T::FN];
 #pragma unroll
     for (int j = 0; j < T::FN; ++j) {
@@ -112,7 +118,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
             float c[4] = {0.f, 0.f, 0.f, 0.f};
             for (int r = 0; r < 4; ++r) if (INTERIOR || n + r < p.N) c[r] = p.colscale[n + r];
 #pragma unroll
-            for (int i = 0; i < T::FM; ++i) { acc[i][j][0] *= c[0]; acc[i][j][1] *= c[1]; acc[i][j][2] *= c[2]; acc[i][j][3] *= c[3]; }
+            for (int i = 0; i < T::FM; ++i) { acc[i][j][0] = __fmul_rn(acc[i][j][0], c[0]); acc[i][j][1] = __fmul_rn(acc[i][j][1], c[1]); acc[i][j][2] = __fmul_rn(acc[i][j][2], c[2]); acc[i][j][3] = __fmul_rn(acc[i][j][3], c[3]); }   // a rounded product in every instantiation (never contracted with the bias add: interior and edge tiles must agree bit for bit)
         }
     }
 #pragma unroll
@@ -127,12 +133,12 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
             arow = p.grp_off + within;
         }
         float4 extra[T::FN];   // residual / row-add operand of this row, all column fragments at once
-        if (INTERIOR && (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_ROWADD_F32)) {
+        if (K32 && INTERIOR && (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_ROWADD_F32)) {
             const float* src = (epi == EPI_BIAS_RESID_F32) ? p.resid + (size_t)orow * p.ldr : p.rowadd + (size_t)arow * p.ldra;
 #pragma unroll
             for (int j = 0; j < T::FN; ++j) extra[j] = *reinterpret_cast<const float4*>(src + n_base + j * 16 + fq * 4);
         }
-        if (INTERIOR && (T::FN % 2 == 0) && (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16)) {
+        if (K16 && INTERIOR && (T::FN % 2 == 0) && (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16)) {
             // bf16 output, interior tile: 16-byte stores.  A lane holds 4 consecutive n per fragment
             // (8 B of bf16); v_permlane16_swap trades quads between the lane rows fq and fq^1 of a
             // fragment PAIR (j, j+1): even-fq lanes end up with 8 consecutive n of fragment j, odd-fq
@@ -163,16 +169,16 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
             if (!INTERIOR && n >= p.N) continue;
             float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
             const bool full = INTERIOR || (n + 3 < p.N);
-            if (epi == EPI_BIAS_GELU_BF16 || epi == EPI_BIAS_GELU_FP8) {
+            if (K16 && (epi == EPI_BIAS_GELU_BF16 || epi == EPI_BIAS_GELU_FP8)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
             }
-            if (epi == EPI_BIAS_GELU_FP8) {   // 4 consecutive n -> one dword of e4m3
+            if (K16 && epi == EPI_BIAS_GELU_FP8) {   // 4 consecutive n -> one dword of e4m3
                 unsigned char* o = reinterpret_cast<unsigned char*>(p.out) + (size_t)orow * p.ldo + n;
                 const unsigned int pk = pack_fp8x4(v[0] * p.out_scale, v[1] * p.out_scale, v[2] * p.out_scale, v[3] * p.out_scale);
                 if (full) *reinterpret_cast<unsigned int*>(o) = pk;
                 else for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] = (unsigned char)(pk >> (8 * r));
-            } else if (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16) {
+            } else if (K16) {
                 bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + (size_t)orow * p.ldo + n;
                 if (full) {
                     u32x2 pk = {OP::pack2(v[0], v[1]), OP::pack2(v[2], v[3])};
@@ -215,13 +221,153 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x4 (&
     }
 }
 
-template <class T, class OP = OpBf16>
+// Edge tiles of the classic kinds where N is a multiple of 4 (every tile but the deep-ring one, which serves ragged widths: T::RAGGED_N): a
+// lane's column quad lies wholly inside or wholly outside the matrix, so the guards are one per fragment row and one per column quad
+// instead of one per element.  The per-element form of gemm_epilogue_impl<..., false> unrolled over 8 x 4 x 4 elements was what spilled
+// (148-312 bytes per lane in the 256 x 256 and 160 x 128 kernels, round 3's whitelist in tests/test_abi.py); this one keeps every
+// GEMM kernel of the library free of scratch.  Same arithmetic, element for element.
+template <class T, class OP, int KIND>
+__device__ __forceinline__ void gemm_epilogue_edge_quads(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
+    const int epi = p.epi;
+    constexpr bool K16 = KIND != 3, K32 = KIND != 0;
+    int orow[T::FM], arow[T::FM];
+    if (p.grp_in > 0) {
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i) {
+            const int m = min(m_base + i * 16 + fr, p.M - 1);
+            const int grp = m / p.grp_in, within = m - grp * p.grp_in;
+            orow[i] = grp * p.grp_out + p.grp_off + within;
+            arow[i] = p.grp_off + within;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i) { orow[i] = m_base + i * 16 + fr; arow[i] = 0; }
+    }
+#pragma unroll
+    for (int j = 0; j < T::FN; ++j) {
+        const int n = n_base + j * 16 + fq * 4;
+        if (n >= p.N) continue;                                  // the whole quad is outside
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        float4 c = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.colscale) c = *reinterpret_cast<const float4*>(p.colscale + n);
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i) {
+            if (m_base + i * 16 + fr >= p.M) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.colscale) { v[0] = __fmul_rn(v[0], c.x); v[1] = __fmul_rn(v[1], c.y); v[2] = __fmul_rn(v[2], c.z); v[3] = __fmul_rn(v[3], c.w); }
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            if (K16 && (epi == EPI_BIAS_GELU_BF16 || epi == EPI_BIAS_GELU_FP8)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (K16 && epi == EPI_BIAS_GELU_FP8) {
+                *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(p.out) + (size_t)orow[i] * p.ldo + n) =
+                    pack_fp8x4(v[0] * p.out_scale, v[1] * p.out_scale, v[2] * p.out_scale, v[3] * p.out_scale);
+            } else if (K16 && (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16)) {
+                u32x2 pk = {OP::pack2(v[0], v[1]), OP::pack2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)orow[i] * p.ldo + n) = pk;
+            } else if (K32) {
+                if (epi == EPI_BIAS_RESID_F32) {           // resid + (acc + bias)
+                    const float4 x = *reinterpret_cast<const float4*>(p.resid + (size_t)orow[i] * p.ldr + n);
+                    v[0] = x.x + v[0]; v[1] = x.y + v[1]; v[2] = x.z + v[2]; v[3] = x.w + v[3];
+                } else if (epi == EPI_BIAS_ROWADD_F32) {   // (acc + bias) + rowadd
+                    const float4 x = *reinterpret_cast<const float4*>(p.rowadd + (size_t)arow[i] * p.ldra + n);
+                    v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+                }
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)orow[i] * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+// The f32-output kinds (EPI_BIAS_RESID_F32 / EPI_BIAS_ROWADD_F32 / EPI_BIAS_F32) on interior tiles (round 4).  In gemm_epilogue_impl a
+// fragment row's residual loads sit behind the previous row's stores (`out` may alias `resid`, so hipcc keeps the order and waits with
+// vmcnt(0) for both, FM times per tile - eight times on the 256 x 256 tile that runs every out-projection / MLP-down GEMM of ViT-L / ViT-H).
+// Here the addend rows are loaded G fragment rows at a time into a ping-pong register set, group g + 1 before group g's stores (see
+// gemm_epilogue_resid_stats_interior).  Same arithmetic in the same order as gemm_epilogue_impl: bit-identical.
+template <class T, int G>
+__device__ __forceinline__ void gemm_epilogue_f32_interior(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq) {
+    constexpr int NG = (T::FM + G - 1) / G;
+    const int epi = p.epi;
+    float4 bias4[T::FN];
+#pragma unroll
+    for (int j = 0; j < T::FN; ++j) bias4[j] = *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + fq * 4);
+    if (p.colscale) {   // fp8 operands: dequantise the accumulators (wave-uniform branch, once per tile)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) {
+            const float4 c = *reinterpret_cast<const float4*>(p.colscale + n_base + j * 16 + fq * 4);
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i) { acc[i][j][0] = __fmul_rn(acc[i][j][0], c.x); acc[i][j][1] = __fmul_rn(acc[i][j][1], c.y); acc[i][j][2] = __fmul_rn(acc[i][j][2], c.z); acc[i][j][3] = __fmul_rn(acc[i][j][3], c.w); }
+        }
+    }
+    int orow[T::FM], arow[T::FM];
+    if (p.grp_in > 0) {   // row remap m -> (m / grp_in) * grp_out + grp_off + m % grp_in (one uniform branch, not one per fragment row)
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i) {
+            const int m = m_base + i * 16 + fr;
+            const int grp = m / p.grp_in, within = m - grp * p.grp_in;
+            orow[i] = grp * p.grp_out + p.grp_off + within;
+            arow[i] = p.grp_off + within;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i) { orow[i] = m_base + i * 16 + fr; arow[i] = 0; }
+    }
+    if (epi == EPI_BIAS_F32) {   // nothing to load
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i) {
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)orow[i] * p.ldo + n_base + fq * 4;
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j)
+                *reinterpret_cast<float4*>(o + j * 16) = make_float4(acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w);
+        }
+        return;
+    }
+    const float* src[T::FM];
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i)
+        src[i] = (epi == EPI_BIAS_ROWADD_F32 ? p.rowadd + (size_t)arow[i] * p.ldra : p.resid + (size_t)orow[i] * p.ldr) + n_base + fq * 4;
+    float4 x[2][G][T::FN];
+#pragma unroll
+    for (int ii = 0; ii < G; ++ii)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j)
+            if (ii < T::FM) x[0][ii][j] = *reinterpret_cast<const float4*>(src[ii] + j * 16);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int ii = 0; ii < G; ++ii)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j)
+                    if ((g + 1) * G + ii < T::FM) x[(g + 1) & 1][ii][j] = *reinterpret_cast<const float4*>(src[(g + 1) * G + ii] + j * 16);
+        }
+#pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            const int i = g * G + ii;
+            if (i >= T::FM) continue;
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)orow[i] * p.ldo + n_base + fq * 4;
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) {
+                const float4 xr = x[g & 1][ii][j];
+                *reinterpret_cast<float4*>(o + j * 16) = make_float4(xr.x + (acc[i][j][0] + bias4[j].x), xr.y + (acc[i][j][1] + bias4[j].y),
+                                                                     xr.z + (acc[i][j][2] + bias4[j].z), xr.w + (acc[i][j][3] + bias4[j].w));
+            }
+        }
+    }
+}
+
+// G: fragment rows per residual-load group of the f32-output kinds (the register budget of the calling kernel)
+template <class T, class OP = OpBf16, int G = 2, int KIND = -1>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base,
                                               int fr, int fq) {
     // wave-uniform: the wave's whole FM*16 x FN*16 patch lies inside the matrix
     const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
-    if (interior) gemm_epilogue_impl<T, true, OP>(p, acc, m_base, n_base, fr, fq);
-    else gemm_epilogue_impl<T, false, OP>(p, acc, m_base, n_base, fr, fq);
+    const bool f32_out = p.epi == EPI_BIAS_RESID_F32 || p.epi == EPI_BIAS_ROWADD_F32 || p.epi == EPI_BIAS_F32;
+    if (KIND != 0 && interior && (KIND == 3 || f32_out)) gemm_epilogue_f32_interior<T, G>(p, acc, m_base, n_base, fr, fq);
+    else if (interior) gemm_epilogue_impl<T, true, OP, (KIND == 3 ? -1 : KIND)>(p, acc, m_base, n_base, fr, fq);
+    else if constexpr (KIND >= 0 && !T::RAGGED_N) gemm_epilogue_edge_quads<T, OP, KIND>(p, acc, m_base, n_base, fr, fq);   // N % 4 == 0 (launch_gemm_variant)
+    else gemm_epilogue_impl<T, false, OP, KIND>(p, acc, m_base, n_base, fr, fq);
 }
 
 // ---- LayerNorm-fold epilogues (their own kernel instantiations: the classic kernels stay as they are).
@@ -294,6 +440,128 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
         m2 += __shfl_xor(m2, 16, 64);
         m2 += __shfl_xor(m2, 32, 64);
         if (fq == 0 && row_ok && ncols > 0) p.ln_part[(size_t)mr * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
+    }
+}
+
+// Interior tiles of the same epilogue (round 4).  The form above issues, per fragment row, four residual loads, waits, then nine
+// stores - and because `out` may alias `resid` (the stream is updated in place) hipcc must keep every row's loads BEHIND the previous
+// row's stores: s_waitcnt vmcnt(0) in front of each row waits for those stores to be acknowledged and then for the loads, FM times in
+// a row (tools/gemm_bench stamps: 7.9 us of "epilogue issue" per 160 x 128 tile against a 14 us K loop; the ISA shows the 5 x
+// [4 loads, vmcnt(0), 9 stores]).  Here the residual rows are loaded G fragment rows at a time into a ping-pong register set, group
+// g + 1 BEFORE the stores of group g are issued (a thread only ever re-reads what it alone writes, so the order is free), and the
+// wait in front of a group is a counted one that leaves the younger stores in flight.  G = FM where the register budget allows
+// (two-stage 160 x 128: every load of the tile in flight at once); the 16-bit copy goes out in 16-byte stores through the
+// fragment-pair lane swap of gemm_epilogue_impl.  Same arithmetic in the same order: bit-identical to the guarded form.
+// Residual rows of a wave's patch loaded BEFORE the K loop (GemmParams::rs_prefetch_from: the workgroups a CU receives second).  A
+// single-round grid of the two-per-CU kernel runs every K loop first and every epilogue after it, chip-wide: 97 MB of residual reads,
+// stream stores and 16-bit copies in the last ~8 us of a 30 us launch (8-9 TB/s: the fabric, not latency - loading all rows of the
+// tile at once at the start of the epilogue changed nothing), while the loops before it barely touch HBM.  With the second workgroup of
+// every CU fetching its residual rows up front (its first K-tile wait also waits for them: vmcnt is in order - it starts ~4 us late,
+// while the first workgroup has the CU's operand path to itself) the two phases of the two workgroups interleave.
+#ifndef IVIT_RS_PREFETCH_ROWS
+#define IVIT_RS_PREFETCH_ROWS 8   // fragment rows held across the K loop (16 registers each; capped at the tile's FM): all five of the 160 x 128 tile = 212 registers, no scratch
+#endif
+template <class T>
+struct RsPrefetch {
+    static constexpr int ROWS = T::FM < IVIT_RS_PREFETCH_ROWS ? T::FM : IVIT_RS_PREFETCH_ROWS;
+    typedef float4 Rows[ROWS][T::FN];   // (a plain array passed by reference: a struct handed on by pointer stayed in scratch memory)
+};
+template <class T>
+__device__ __forceinline__ void rs_prefetch_load(const GemmParams& p, int m_base, int n_base, int fr, int fq, typename RsPrefetch<T>::Rows& x) {
+    const float* src = p.resid + (size_t)(m_base + fr) * p.ldr + n_base + fq * 4;
+#pragma unroll
+    for (int i = 0; i < RsPrefetch<T>::ROWS; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) x[i][j] = *reinterpret_cast<const float4*>(src + (size_t)i * 16 * p.ldr + j * 16);
+}
+
+template <class T, class OP, int G>
+__device__ __forceinline__ void gemm_epilogue_resid_stats_interior(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
+                                                                   const typename RsPrefetch<T>::Rows& pfx, bool pf_have) {
+    static_assert(T::FN * 16 == 64 && T::FN % 2 == 0, "one statistics slot per wave column; fragment pairs for the 16-byte stores");
+    constexpr int NG = (T::FM + G - 1) / G;
+    const int slot = n_base >> 6;
+    float4 bias4[T::FN];
+#pragma unroll
+    for (int j = 0; j < T::FN; ++j) bias4[j] = *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + fq * 4);
+    int orow[T::FM];
+    const float* src[T::FM];
+    if (p.grp_in > 0) {   // EPI_BIAS_ROWADD_STATS: GEMM row -> token row of its image, the addend is the table row (position embedding)
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i) {
+            const int m = m_base + i * 16 + fr;
+            const int grp = m / p.grp_in, within = m - grp * p.grp_in;
+            orow[i] = grp * p.grp_out + p.grp_off + within;
+            src[i] = p.rowadd + (size_t)(p.grp_off + within) * p.ldra + n_base + fq * 4;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i) {
+            orow[i] = m_base + i * 16 + fr;
+            src[i] = p.resid + (size_t)orow[i] * p.ldr + n_base + fq * 4;
+        }
+    }
+    float4 x[2][G][T::FN];
+    const bool pre = G >= T::FM && pf_have;   // the first residual rows of the patch are already in registers (wave-uniform)
+    {   // group 0: the first ROWS fragment rows may be in registers already (copied unconditionally, then overwritten by the loads of a workgroup
+        // that did not prefetch: a `pre ? registers : load` per element became ONE load through a pointer phi and kept the array in scratch)
+        constexpr int PR = RsPrefetch<T>::ROWS;
+#pragma unroll
+        for (int ii = 0; ii < G; ++ii)
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j)
+                if (ii < T::FM && ii < PR && G >= T::FM) x[0][ii][j] = pfx[ii < PR ? ii : 0][j];
+#pragma unroll
+        for (int ii = 0; ii < G; ++ii)
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j)
+                if (ii < T::FM && !(pre && ii < PR)) x[0][ii][j] = *reinterpret_cast<const float4*>(src[ii] + j * 16);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int ii = 0; ii < G; ++ii)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j)
+                    if ((g + 1) * G + ii < T::FM) x[(g + 1) & 1][ii][j] = *reinterpret_cast<const float4*>(src[(g + 1) * G + ii] + j * 16);
+        }
+#pragma unroll
+        for (int ii = 0; ii < G; ++ii) {
+            const int i = g * G + ii;
+            if (i >= T::FM) continue;
+            const int mr = orow[i];
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)mr * p.ldo + n_base + fq * 4;
+            bf16_t* ob = p.xb + (size_t)mr * p.ldxb + n_base;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) {
+                const float4 xr = x[g & 1][ii][j];
+                const float v[4] = {xr.x + (acc[i][j][0] + bias4[j].x), xr.y + (acc[i][j][1] + bias4[j].y),
+                                    xr.z + (acc[i][j][2] + bias4[j].z), xr.w + (acc[i][j][3] + bias4[j].w)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[i][j][r] = v[r]; sum += v[r]; }
+                *reinterpret_cast<float4*>(o + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int j = 0; j < T::FN; j += 2) {   // 16-bit copy: 16-byte stores (lane rows fq / fq ^ 1 trade quads of a fragment pair)
+                const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(acc[i][j][0], acc[i][j][1]), OP::pack2(acc[i][j + 1][0], acc[i][j + 1][1]), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(acc[i][j][2], acc[i][j][3]), OP::pack2(acc[i][j + 1][2], acc[i][j + 1][3]), false, false);
+                u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
+                *reinterpret_cast<u32x4*>(ob + (j + (fq & 1)) * 16 + (fq & ~1) * 4) = pk;
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float lmean = sum / 64.0f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - lmean; m2 = fmaf(d, d, m2); }
+            m2 += __shfl_xor(m2, 16, 64);
+            m2 += __shfl_xor(m2, 32, 64);
+            if (fq == 0) p.ln_part[(size_t)mr * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
+        }
     }
 }
 
@@ -433,21 +701,32 @@ __device__ __forceinline__ void ln_tile_stats_prefetch(const GemmParams& p, int 
     for (int l = 0; l < 6; ++l) first[l] = pr[l];
 }
 
-// EK = 0: the classic epilogues (kind chosen at run time); 1: EPI_BIAS_RESID_STATS; 2: EPI_LNFOLD_*.
+// EK = 0: the classic 16-bit / fp8 output epilogues (kind chosen at run time); 3: the classic f32 output epilogues; 1: EPI_BIAS_RESID_STATS; 2: EPI_LNFOLD_*.
 // (One kernel per classic kind was tried too: no gain at the ViT-B shapes, 5-15 % slower at the ViT-H shapes.)
-template <class T, int EK, class OP = OpBf16>
+// RSG: fragment rows per residual-load group of the interior EPI_BIAS_RESID_STATS epilogue (register budget of the calling kernel)
+template <class T, int EK, class OP = OpBf16, int RSG = T::FM>
 __device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
-                                                     const float2* tile_stats = nullptr) {
+                                                     const float2* tile_stats, const typename RsPrefetch<T>::Rows& pfx, bool pf_have) {
     const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
-    if constexpr (EK == 0) {
-        gemm_epilogue<T, OP>(p, acc, m_base, n_base, fr, fq);
+    if constexpr (EK == 0 || EK == 3 || EK == -1) {
+        gemm_epilogue<T, OP, (RSG > 2 ? 2 : RSG), EK>(p, acc, m_base, n_base, fr, fq);
     } else if constexpr (EK == 1) {
-        if (interior) gemm_epilogue_resid_stats<T, true, OP>(p, acc, m_base, n_base, fr, fq);
+#ifdef IVIT_GEMM_ABLATIONS   // A/B in one binary (tools/gemm_bench argv[5] = 7, IVIT_OLD_EPI=1 with tools/libivit_abl.so): round 3's row-by-row form
+        if (interior && p.debug == 7) { gemm_epilogue_resid_stats<T, true, OP>(p, acc, m_base, n_base, fr, fq); return; }
+#endif
+        if (interior) gemm_epilogue_resid_stats_interior<T, OP, RSG>(p, acc, m_base, n_base, fr, fq, pfx, pf_have);
         else gemm_epilogue_resid_stats<T, false, OP>(p, acc, m_base, n_base, fr, fq);
     } else {
         if (interior) gemm_epilogue_lnfold<T, true, OP>(p, acc, m_base, n_base, fr, fq, tile_stats);
         else gemm_epilogue_lnfold<T, false, OP>(p, acc, m_base, n_base, fr, fq, tile_stats);
     }
+}
+
+template <class T, int EK, class OP = OpBf16, int RSG = T::FM>
+__device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
+                                                     const float2* tile_stats = nullptr) {
+    typename RsPrefetch<T>::Rows none;   // never read (pf_have = false)
+    gemm_epilogue_family<T, EK, OP, RSG>(p, acc, m_base, n_base, fr, fq, tile_stats, none, false);
 }
 
 // XCD-aware, bijective block -> tile map: blocks that share an XCD (id % 8) get a contiguous run of
@@ -541,6 +820,18 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     }
     const int fr = lane & 15;   // fragment row (m for the A^T operand, n for the W operand)
     const int fq = lane >> 4;   // 16-B k-chunk inside a 32-deep MFMA step
+    typename RsPrefetch<T>::Rows rs_x;
+    bool rs_have = false;
+    if constexpr (EK == 1) {
+#pragma unroll
+        for (int i = 0; i < RsPrefetch<T>::ROWS; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) rs_x[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if constexpr (EK == 1) {   // see RsPrefetch: the second workgroup of a CU brings its residual rows in before its K loop
+        rs_have = p.rs_prefetch_from > 0 && (int)blockIdx.x >= p.rs_prefetch_from && p.grp_in == 0 && m0 + T::BM <= p.M && n0 + T::BN <= p.N;
+        if (rs_have) rs_prefetch_load<T>(p, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, rs_x);
+    }
     IVIT_BODY_STAMP(1);
 
     // one K-tile; FOLD (first iteration of the LayerNorm-fold kernels only, a separate copy of the body so that the loop proper
@@ -604,7 +895,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     }
     for (int t = t_first; t < nt; ++t) ktile(t, std::false_type{});
     IVIT_BODY_STAMP(2);
-    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
+    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16, rs_x, rs_have);
     IVIT_BODY_STAMP(3);
 #ifdef IVIT_GEMM_ABLATIONS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -676,7 +967,7 @@ __device__ __forceinline__ void gemm_body_sb(const GemmParams& p, char* smem) {
                     for (int j = 0; j < T::FN; ++j) acc[i][j] = OP::mfma(wf[j][kk], af[i][kk], acc[i][j]);
         }
     }
-    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);
+    gemm_epilogue_family<T, EK, OP, (T::FM > 4 ? 1 : 2)>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16);   // 168 registers: one fragment row ahead at FM = 5
 }
 
 // ---- small-M tile with a deep DMA ring (the interactive path: one to a few images, M = 197 ... ~1000 token rows).
@@ -689,6 +980,7 @@ template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int STAGES_>
 struct GemmTileDeep : GemmTile<WAVES_M_, WAVES_N_, FM_, FN_> {
     using Base = GemmTile<WAVES_M_, WAVES_N_, FM_, FN_>;
     static constexpr int STAGES = STAGES_;
+    static constexpr bool RAGGED_N = true;
     static constexpr int LDS_BYTES = STAGES * Base::STAGE_BYTES;
     static constexpr int PIECES_PER_WAVE = (Base::A_PIECES + Base::W_PIECES) / Base::WAVES;
     static_assert(Base::A_PIECES % Base::WAVES == 0 && Base::W_PIECES % Base::WAVES == 0, "every wave must issue the same number of DMA pieces");

@@ -48,6 +48,8 @@ struct GemmParams {
     bf16_t* xb; int ldxb;           // EPI_BIAS_RESID_STATS: bf16 copy of the new residual rows
     const float* ln_s;              // EPI_LNFOLD_*: s[n] = sum_k W'[n][k]          (bias = c[n])
     float ln_eps; int ln_dim;       // EPI_LNFOLD_*: LayerNorm epsilon and width (= K of this GEMM)
+    int rs_prefetch_from;           // EPI_BIAS_RESID_STATS on the two-stage tile: workgroups with blockIdx.x >= this (> 0) load their residual rows BEFORE the
+                                    // K loop (the workgroups a CU receives second, when every CU gets one before any gets two); 0 = off.  gemm_kernel.h: RsPrefetch
     int debug;                      // microbenchmark ablations only (0 in the product): 1 = no DMA in the K loop, 2 = no MFMA
     unsigned long long* stamps;     // microbenchmark builds only: per-block s_memrealtime stamps (nullptr in the product)
     int order;                      // microbenchmark builds only: 1 = row bands per XCD (tile_coords_banded), 2 = pairs sharing a CU (gemm_body)

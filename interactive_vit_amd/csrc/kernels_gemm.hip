@@ -11,7 +11,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <string>
 #include <set>
 #include <utility>
 
@@ -31,7 +33,14 @@ using Tile256 = GemmTile<2, 4, 8, 4>;   // 256 x 256, 8 waves, plain double buff
         extern __shared__ __attribute__((aligned(16))) char smem[];                          \
         gemm_body_sb<TILE, FP8, EK, OP>(p, smem);                                             \
     }
+// (_f32 = the classic f32-output epilogues - EPI_BIAS_F32 / EPI_BIAS_RESID_F32 / EPI_BIAS_ROWADD_F32 - as their own instantiations: gemm_kernel.h, KIND)
 IVIT_SB_KERNEL(ivit_gemm_bf16_128x128x64_sb, Tile128, false, 0, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_bf16_128x128x64_sb_f32, Tile128, false, 3, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_bf16_160x128x64_sb_f32, Tile160, false, 3, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_f16_128x128x64_sb_f32, Tile128, false, 3, OpF16)
+IVIT_SB_KERNEL(ivit_gemm_f16_160x128x64_sb_f32, Tile160, false, 3, OpF16)
+IVIT_SB_KERNEL(ivit_gemm_fp8_128x128x128_sb_f32, Tile128, true, 3, OpBf16)
+IVIT_SB_KERNEL(ivit_gemm_fp8_160x128x128_sb_f32, Tile160, true, 3, OpBf16)
 IVIT_SB_KERNEL(ivit_gemm_bf16_128x128x64_sb_rs, Tile128, false, 1, OpBf16)
 IVIT_SB_KERNEL(ivit_gemm_bf16_128x128x64_sb_lf, Tile128, false, 2, OpBf16)
 IVIT_SB_KERNEL(ivit_gemm_bf16_160x128x64_sb, Tile160, false, 0, OpBf16)
@@ -56,6 +65,8 @@ IVIT_SB_KERNEL(ivit_gemm_fp8_160x128x128_sb, Tile160, true, 0, OpBf16)
         gemm_body<TILE, false, EK, OP>(p, smem);                                              \
     }
 IVIT_2ST_KERNEL(ivit_gemm_bf16_160x128x64, Tile160, 0, OpBf16)
+IVIT_2ST_KERNEL(ivit_gemm_bf16_160x128x64_f32, Tile160, 3, OpBf16)
+IVIT_2ST_KERNEL(ivit_gemm_f16_160x128x64_f32, Tile160, 3, OpF16)
 IVIT_2ST_KERNEL(ivit_gemm_bf16_160x128x64_rs, Tile160, 1, OpBf16)
 IVIT_2ST_KERNEL(ivit_gemm_bf16_160x128x64_lf, Tile160, 2, OpBf16)
 IVIT_2ST_KERNEL(ivit_gemm_f16_160x128x64, Tile160, 0, OpF16)
@@ -75,6 +86,9 @@ IVIT_256S_KERNEL(ivit_gemm_f16_256x256x64_stag, false, 0, OpF16)
 IVIT_256S_KERNEL(ivit_gemm_f16_256x256x64_stag_rs, false, 1, OpF16)
 IVIT_256S_KERNEL(ivit_gemm_f16_256x256x64_stag_lf, false, 2, OpF16)
 IVIT_256S_KERNEL(ivit_gemm_fp8_256x256x128_stag, true, 0, OpBf16)
+IVIT_256S_KERNEL(ivit_gemm_bf16_256x256x64_stag_f32, false, 3, OpBf16)
+IVIT_256S_KERNEL(ivit_gemm_f16_256x256x64_stag_f32, false, 3, OpF16)
+IVIT_256S_KERNEL(ivit_gemm_fp8_256x256x128_stag_f32, true, 3, OpBf16)
 #undef IVIT_256S_KERNEL
 
 // small-M tile with a deep DMA ring (gemm_kernel.h: gemm_body_deep): 64 x 128, 8 waves of 16 x 64 (two per SIMD: one wave's DMA issue
@@ -87,6 +101,8 @@ using Tile64D = GemmTileDeep<4, 2, 1, 4, 4>;
         gemm_body_deep<Tile64D, EK, OP>(p, smem);                                             \
     }
 IVIT_DEEP_KERNEL(ivit_gemm_bf16_64x128x64_deep, 0, OpBf16)
+IVIT_DEEP_KERNEL(ivit_gemm_bf16_64x128x64_deep_f32, 3, OpBf16)
+IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_f32, 3, OpF16)
 IVIT_DEEP_KERNEL(ivit_gemm_bf16_64x128x64_deep_rs, 1, OpBf16)
 IVIT_DEEP_KERNEL(ivit_gemm_bf16_64x128x64_deep_lf, 2, OpBf16)
 IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep, 0, OpF16)
@@ -96,7 +112,7 @@ IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_lf, 2, OpF16)
 
 #ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost, and timing ablations
 // the two-stage form of the 128 x 128 tile (the 160 x 128 one is a product kernel; it is the bit-identity reference of tools/gemm_bench)
-IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64, Tile128, 0, OpBf16)
+IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64, Tile128, -1, OpBf16)
 IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64_rs, Tile128, 1, OpBf16)
 IVIT_2ST_KERNEL(ivit_gemm_bf16_128x128x64_lf, Tile128, 2, OpBf16)
 // round 3 (late): single-stage tiles with MORE rows per workgroup, two workgroups per CU - fewer operand bytes per FLOP on the CU's vector-memory
@@ -108,10 +124,10 @@ using Tile192 = GemmTile<2, 2, 6, 4>;
         extern __shared__ __attribute__((aligned(16))) char smem[];                          \
         gemm_body_sb<TILE, false, EK, OpBf16>(p, smem);                                       \
     }
-IVIT_SB2_KERNEL(ivit_gemm_bf16_256x128x64_sb, Tile256x128, 0)
+IVIT_SB2_KERNEL(ivit_gemm_bf16_256x128x64_sb, Tile256x128, -1)
 IVIT_SB2_KERNEL(ivit_gemm_bf16_256x128x64_sb_rs, Tile256x128, 1)
 IVIT_SB2_KERNEL(ivit_gemm_bf16_256x128x64_sb_lf, Tile256x128, 2)
-IVIT_SB2_KERNEL(ivit_gemm_bf16_192x128x64_sb, Tile192, 0)
+IVIT_SB2_KERNEL(ivit_gemm_bf16_192x128x64_sb, Tile192, -1)
 IVIT_SB2_KERNEL(ivit_gemm_bf16_192x128x64_sb_rs, Tile192, 1)
 IVIT_SB2_KERNEL(ivit_gemm_bf16_192x128x64_sb_lf, Tile192, 2)
 // persistent two-per-CU workgroups (study/gemmp_kernel.h; round 3): bit-identical, SLOWER (mlp1 + fold + GELU 92.8 us against 80.0; section
@@ -138,12 +154,12 @@ using Tile160W8 = GemmTile<2, 4, 5, 2>;    // wave tile 80 x 32
         extern __shared__ __attribute__((aligned(16))) char smem[];                          \
         gemm_body<TILE, false, EK>(p, smem);                                                  \
     }
-IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8a, Tile128W8A, 0)
+IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8a, Tile128W8A, -1)
 IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8a_lf, Tile128W8A, 2)
-IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8b, Tile128W8B, 0)
+IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8b, Tile128W8B, -1)
 IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8b_lf, Tile128W8B, 2)
 IVIT_W8_KERNEL(ivit_gemm_bf16_128x128x64_w8b_rs, Tile128W8B, 1)
-IVIT_W8_KERNEL(ivit_gemm_bf16_160x128x64_w8, Tile160W8, 0)
+IVIT_W8_KERNEL(ivit_gemm_bf16_160x128x64_w8, Tile160W8, -1)
 IVIT_W8_KERNEL(ivit_gemm_bf16_160x128x64_w8_lf, Tile160W8, 2)
 #undef IVIT_W8_KERNEL
 // persistent 256 x 128 tile with the previous tile's epilogue interleaved into the main loop (study/gemmpe_kernel.h; round 2, ties)
@@ -167,7 +183,7 @@ __global__ __launch_bounds__(Tile160x256::THREADS, 2) void ivit_gemm_bf16_160x25
 }
 __global__ __launch_bounds__(Tile256::THREADS, 2) void ivit_gemm_bf16_256x256x64(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_body<Tile256>(p, smem);
+    gemm_body<Tile256, false, -1>(p, smem);
 }
 __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_bf16_256x256x64_pipe(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -194,6 +210,14 @@ __global__ __launch_bounds__(Tile256P::THREADS, 2) void ivit_gemm_256stag_nomfma
     gemm256s_body<2>(p, smem);
 }
 #endif
+
+// epilogue family of a call: 0 classic 16-bit / fp8 outputs, 3 classic f32 outputs ("_f32"), 1 residual + statistics ("_rs"), 2 LayerNorm fold ("_lf")
+static int gemm_family(int epi) {
+    if (epi == EPI_BIAS_RESID_STATS || epi == EPI_BIAS_ROWADD_STATS) return 1;
+    if (epi == EPI_LNFOLD_BF16 || epi == EPI_LNFOLD_GELU_BF16) return 2;
+    if (epi == EPI_BIAS_F32 || epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_ROWADD_F32) return 3;
+    return 0;
+}
 
 const char* gemm_variant_name(int v) {
     switch (v) {
@@ -276,6 +300,7 @@ bool gemm_prefers_256(int M, int N, int K) {
 // shape fit one round of one workgroup per CU, every K-tile of a shallow ring is a DMA round trip - the deep-ring tile takes
 // those (tools/gemm_bench at M = 197: qkv 10.8 -> 7.3 us, proj 13.2 -> 8.1, mlp1 12.1 -> 7.9, mlp2 33.9 -> 19.3; bit-identical).
 int gemm_pick_variant(int M, int N, int K) {
+    if (N % 4) return GEMM_TILE_64D;   // ragged widths (a classifier of any size): the only tile whose edge epilogue guards single elements
     if (K >= 2 * GEMM_BK && ceil_div(M, Tile64D::BM) * ceil_div(N, Tile64D::BN) <= 256) return GEMM_TILE_64D;
     if (gemm_prefers_256(M, N, K)) return GEMM_TILE_256S;
     // 160 x 128 wherever the grid gives every CU work (fewer operand bytes per FLOP than 128 x 128, and all workgroups of a CU share its
@@ -413,13 +438,28 @@ bool gemm_pe_supported(const GemmParams&) { return false; }
 bool gemm_persist_supported(const GemmParams&) { return false; }
 #endif
 
-hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream) {
+// EPI_BIAS_RESID_STATS on the two-stage 160 x 128 tile, a grid of one to two workgroups per CU (out-projection / MLP down at ViT-B/16 B = 64): the
+// workgroups a CU receives second fetch their residual rows before their K loop (gemm_kernel.h: RsPrefetch).  IVIT_RS_PREFETCH=0: measurement knob.
+static int rs_prefetch_from(const GemmParams& p, int variant) {
+    static const int mode = [] { const char* v = getenv("IVIT_RS_PREFETCH"); return v ? atoi(v) : 1; }();
+    if (!mode || variant != GEMM_TILE_160 || p.epi != EPI_BIAS_RESID_STATS || p.grp_in != 0) return 0;
+    const int cus = device_cu_count(), tiles = ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN);
+    return (tiles > cus && tiles <= 2 * cus) ? cus : 0;
+}
+
+hipError_t launch_gemm_variant(const GemmParams& p_in, int variant, hipStream_t stream) {
+    GemmParams p = p_in;
+    if (p.rs_prefetch_from == 0) p.rs_prefetch_from = rs_prefetch_from(p, variant);
+#ifdef IVIT_GEMM_ABLATIONS
+    { static const int old_epi = [] { const char* v = getenv("IVIT_OLD_EPI"); return v ? atoi(v) : 0; }(); if (old_epi && !p.debug) p.debug = 7; }
+#endif
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (p.K <= 0 || p.K % GEMM_BK != 0) return hipErrorInvalidValue;
     if ((p.lda % 8) || (p.ldw % 8)) return hipErrorInvalidValue;   // 16-B aligned rows for the DMA
     if ((p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
-    const int family = (p.epi == EPI_BIAS_RESID_STATS || p.epi == EPI_BIAS_ROWADD_STATS) ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
-    if (family) {   // LayerNorm-fold epilogues: their own instantiations of the product tiles
+    if ((p.N % 4) && variant != GEMM_TILE_64D) return hipErrorInvalidValue;   // only the deep-ring tile guards single elements at the N edge
+    const int family = gemm_family(p.epi);
+    if (family == 1 || family == 2) {   // LayerNorm-fold epilogues: their own instantiations of the product tiles
         const bool remap = p.epi == EPI_BIAS_ROWADD_STATS;
         if ((p.grp_in != 0) != remap) return hipErrorInvalidValue;
         if (family == 1 && (!p.ln_part || !(remap ? p.rowadd : p.resid) || !p.xb || (p.ldxb % 4) || (remap && (p.ldra % 4)))) return hipErrorInvalidValue;
@@ -427,30 +467,30 @@ hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t str
     }
 #ifdef IVIT_GEMM_ABLATIONS
     {
-        const hipError_t e = launch_study_variant(p, variant, family, stream);
+        const hipError_t e = launch_study_variant(p, variant, family == 3 ? 0 : family, stream);
         if (e != hipErrorNotSupported) return e;
     }
 #endif
     // _lf kernels keep (mean, rstd) of their tile's rows in BM * 8 bytes of LDS behind the operand stages
-#define IVIT_PICK3(T_, LAUNCH, K0, K1, K2) (family == 0 ? LAUNCH<T_>(K0, p, stream, 0) : family == 1 ? LAUNCH<T_>(K1, p, stream, 0) : LAUNCH<T_>(K2, p, stream, T_::BM * 8))
+#define IVIT_PICK4(T_, LAUNCH, K0, K1, K2, K3) (family == 0 ? LAUNCH<T_>(K0, p, stream, 0) : family == 1 ? LAUNCH<T_>(K1, p, stream, 0) : family == 2 ? LAUNCH<T_>(K2, p, stream, T_::BM * 8) : LAUNCH<T_>(K3, p, stream, 0))
     if (p.f16) {
         switch (variant) {
-            case GEMM_TILE_128SB: return IVIT_PICK3(Tile128, launch_sb, ivit_gemm_f16_128x128x64_sb, ivit_gemm_f16_128x128x64_sb_rs, ivit_gemm_f16_128x128x64_sb_lf);
-            case GEMM_TILE_160SB: return IVIT_PICK3(Tile160, launch_sb, ivit_gemm_f16_160x128x64_sb, ivit_gemm_f16_160x128x64_sb_rs, ivit_gemm_f16_160x128x64_sb_lf);
-            case GEMM_TILE_160: return IVIT_PICK3(Tile160, launch_tile, ivit_gemm_f16_160x128x64, ivit_gemm_f16_160x128x64_rs, ivit_gemm_f16_160x128x64_lf);
-            case GEMM_TILE_256S: return IVIT_PICK3(Tile256P, launch_tile, ivit_gemm_f16_256x256x64_stag, ivit_gemm_f16_256x256x64_stag_rs, ivit_gemm_f16_256x256x64_stag_lf);
-            case GEMM_TILE_64D: return IVIT_PICK3(Tile64D, launch_tile, ivit_gemm_f16_64x128x64_deep, ivit_gemm_f16_64x128x64_deep_rs, ivit_gemm_f16_64x128x64_deep_lf);
+            case GEMM_TILE_128SB: return IVIT_PICK4(Tile128, launch_sb, ivit_gemm_f16_128x128x64_sb, ivit_gemm_f16_128x128x64_sb_rs, ivit_gemm_f16_128x128x64_sb_lf, ivit_gemm_f16_128x128x64_sb_f32);
+            case GEMM_TILE_160SB: return IVIT_PICK4(Tile160, launch_sb, ivit_gemm_f16_160x128x64_sb, ivit_gemm_f16_160x128x64_sb_rs, ivit_gemm_f16_160x128x64_sb_lf, ivit_gemm_f16_160x128x64_sb_f32);
+            case GEMM_TILE_160: return IVIT_PICK4(Tile160, launch_tile, ivit_gemm_f16_160x128x64, ivit_gemm_f16_160x128x64_rs, ivit_gemm_f16_160x128x64_lf, ivit_gemm_f16_160x128x64_f32);
+            case GEMM_TILE_256S: return IVIT_PICK4(Tile256P, launch_tile, ivit_gemm_f16_256x256x64_stag, ivit_gemm_f16_256x256x64_stag_rs, ivit_gemm_f16_256x256x64_stag_lf, ivit_gemm_f16_256x256x64_stag_f32);
+            case GEMM_TILE_64D: return IVIT_PICK4(Tile64D, launch_tile, ivit_gemm_f16_64x128x64_deep, ivit_gemm_f16_64x128x64_deep_rs, ivit_gemm_f16_64x128x64_deep_lf, ivit_gemm_f16_64x128x64_deep_f32);
         }
         return hipErrorInvalidValue;
     }
     switch (variant) {
-        case GEMM_TILE_128SB: return IVIT_PICK3(Tile128, launch_sb, ivit_gemm_bf16_128x128x64_sb, ivit_gemm_bf16_128x128x64_sb_rs, ivit_gemm_bf16_128x128x64_sb_lf);
-        case GEMM_TILE_160SB: return IVIT_PICK3(Tile160, launch_sb, ivit_gemm_bf16_160x128x64_sb, ivit_gemm_bf16_160x128x64_sb_rs, ivit_gemm_bf16_160x128x64_sb_lf);
-        case GEMM_TILE_160: return IVIT_PICK3(Tile160, launch_tile, ivit_gemm_bf16_160x128x64, ivit_gemm_bf16_160x128x64_rs, ivit_gemm_bf16_160x128x64_lf);
-        case GEMM_TILE_256S: return IVIT_PICK3(Tile256P, launch_tile, ivit_gemm_bf16_256x256x64_stag, ivit_gemm_bf16_256x256x64_stag_rs, ivit_gemm_bf16_256x256x64_stag_lf);
-        case GEMM_TILE_64D: return IVIT_PICK3(Tile64D, launch_tile, ivit_gemm_bf16_64x128x64_deep, ivit_gemm_bf16_64x128x64_deep_rs, ivit_gemm_bf16_64x128x64_deep_lf);
+        case GEMM_TILE_128SB: return IVIT_PICK4(Tile128, launch_sb, ivit_gemm_bf16_128x128x64_sb, ivit_gemm_bf16_128x128x64_sb_rs, ivit_gemm_bf16_128x128x64_sb_lf, ivit_gemm_bf16_128x128x64_sb_f32);
+        case GEMM_TILE_160SB: return IVIT_PICK4(Tile160, launch_sb, ivit_gemm_bf16_160x128x64_sb, ivit_gemm_bf16_160x128x64_sb_rs, ivit_gemm_bf16_160x128x64_sb_lf, ivit_gemm_bf16_160x128x64_sb_f32);
+        case GEMM_TILE_160: return IVIT_PICK4(Tile160, launch_tile, ivit_gemm_bf16_160x128x64, ivit_gemm_bf16_160x128x64_rs, ivit_gemm_bf16_160x128x64_lf, ivit_gemm_bf16_160x128x64_f32);
+        case GEMM_TILE_256S: return IVIT_PICK4(Tile256P, launch_tile, ivit_gemm_bf16_256x256x64_stag, ivit_gemm_bf16_256x256x64_stag_rs, ivit_gemm_bf16_256x256x64_stag_lf, ivit_gemm_bf16_256x256x64_stag_f32);
+        case GEMM_TILE_64D: return IVIT_PICK4(Tile64D, launch_tile, ivit_gemm_bf16_64x128x64_deep, ivit_gemm_bf16_64x128x64_deep_rs, ivit_gemm_bf16_64x128x64_deep_lf, ivit_gemm_bf16_64x128x64_deep_f32);
     }
-#undef IVIT_PICK3
+#undef IVIT_PICK4
     return hipErrorInvalidValue;
 }
 
@@ -461,39 +501,39 @@ static int fp8_tile(const GemmParams& p) {
 }
 
 const char* gemm_fp8_kernel_name(const GemmParams& p) {
+    const bool f32 = gemm_family(p.epi) == 3;
     switch (fp8_tile(p)) {
-        case GEMM_TILE_256S: return "ivit_gemm_fp8_256x256x128_stag";
-        case GEMM_TILE_160SB: return "ivit_gemm_fp8_160x128x128_sb";
+        case GEMM_TILE_256S: return f32 ? "ivit_gemm_fp8_256x256x128_stag_f32" : "ivit_gemm_fp8_256x256x128_stag";
+        case GEMM_TILE_160SB: return f32 ? "ivit_gemm_fp8_160x128x128_sb_f32" : "ivit_gemm_fp8_160x128x128_sb";
     }
-    return "ivit_gemm_fp8_128x128x128_sb";
+    return f32 ? "ivit_gemm_fp8_128x128x128_sb_f32" : "ivit_gemm_fp8_128x128x128_sb";
 }
 
 const char* gemm_kernel_name(const GemmParams& p) {
     const int v = gemm_pick_variant(p.M, p.N, p.K);
-    const int family = (p.epi == EPI_BIAS_RESID_STATS || p.epi == EPI_BIAS_ROWADD_STATS) ? 1 : (p.epi == EPI_LNFOLD_BF16 || p.epi == EPI_LNFOLD_GELU_BF16) ? 2 : 0;
-    static const char* names[2][5][3] = {
-        {{"ivit_gemm_bf16_64x128x64_deep", "ivit_gemm_bf16_64x128x64_deep_rs", "ivit_gemm_bf16_64x128x64_deep_lf"},
-         {"ivit_gemm_bf16_128x128x64_sb", "ivit_gemm_bf16_128x128x64_sb_rs", "ivit_gemm_bf16_128x128x64_sb_lf"},
-         {"ivit_gemm_bf16_160x128x64_sb", "ivit_gemm_bf16_160x128x64_sb_rs", "ivit_gemm_bf16_160x128x64_sb_lf"},
-         {"ivit_gemm_bf16_256x256x64_stag", "ivit_gemm_bf16_256x256x64_stag_rs", "ivit_gemm_bf16_256x256x64_stag_lf"},
-         {"ivit_gemm_bf16_160x128x64", "ivit_gemm_bf16_160x128x64_rs", "ivit_gemm_bf16_160x128x64_lf"}},
-        {{"ivit_gemm_f16_64x128x64_deep", "ivit_gemm_f16_64x128x64_deep_rs", "ivit_gemm_f16_64x128x64_deep_lf"},
-         {"ivit_gemm_f16_128x128x64_sb", "ivit_gemm_f16_128x128x64_sb_rs", "ivit_gemm_f16_128x128x64_sb_lf"},
-         {"ivit_gemm_f16_160x128x64_sb", "ivit_gemm_f16_160x128x64_sb_rs", "ivit_gemm_f16_160x128x64_sb_lf"},
-         {"ivit_gemm_f16_256x256x64_stag", "ivit_gemm_f16_256x256x64_stag_rs", "ivit_gemm_f16_256x256x64_stag_lf"},
-         {"ivit_gemm_f16_160x128x64", "ivit_gemm_f16_160x128x64_rs", "ivit_gemm_f16_160x128x64_lf"}}};
-    return names[p.f16 ? 1 : 0][v == GEMM_TILE_64D ? 0 : v == GEMM_TILE_128SB ? 1 : v == GEMM_TILE_160SB ? 2 : v == GEMM_TILE_160 ? 4 : 3][family];
+    const int family = gemm_family(p.epi);
+    static const char* base[2][5] = {{"ivit_gemm_bf16_64x128x64_deep", "ivit_gemm_bf16_128x128x64_sb", "ivit_gemm_bf16_160x128x64_sb", "ivit_gemm_bf16_256x256x64_stag", "ivit_gemm_bf16_160x128x64"},
+                                      {"ivit_gemm_f16_64x128x64_deep", "ivit_gemm_f16_128x128x64_sb", "ivit_gemm_f16_160x128x64_sb", "ivit_gemm_f16_256x256x64_stag", "ivit_gemm_f16_160x128x64"}};
+    static const char* suffix[4] = {"", "_rs", "_lf", "_f32"};
+    static std::mutex mu;
+    static std::map<std::pair<const char*, int>, std::string> names;   // interned: callers keep the pointer
+    const char* b = base[p.f16 ? 1 : 0][v == GEMM_TILE_64D ? 0 : v == GEMM_TILE_128SB ? 1 : v == GEMM_TILE_160SB ? 2 : v == GEMM_TILE_160 ? 4 : 3];
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = names.find({b, family});
+    if (it == names.end()) it = names.emplace(std::make_pair(b, family), std::string(b) + suffix[family]).first;
+    return it->second.c_str();
 }
 
 hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (p.K <= 0 || p.K % 128 != 0 || !p.colscale) return hipErrorInvalidValue;
     if ((p.lda % 16) || (p.ldw % 16) || (p.ldo % 4) || (p.resid && (p.ldr % 4))) return hipErrorInvalidValue;
+    const bool f32 = gemm_family(p.epi) == 3;
     switch (fp8_tile(p)) {
-        case GEMM_TILE_256S: return launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag, p, stream);
-        case GEMM_TILE_160SB: return launch_sb<Tile160>(ivit_gemm_fp8_160x128x128_sb, p, stream);
+        case GEMM_TILE_256S: return f32 ? launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag_f32, p, stream) : launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag, p, stream);
+        case GEMM_TILE_160SB: return f32 ? launch_sb<Tile160>(ivit_gemm_fp8_160x128x128_sb_f32, p, stream) : launch_sb<Tile160>(ivit_gemm_fp8_160x128x128_sb, p, stream);
     }
-    return launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb, p, stream);
+    return f32 ? launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb_f32, p, stream) : launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb, p, stream);
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {

@@ -23,6 +23,7 @@
 namespace ivit {
 
 struct Tile160x256 {
+    static constexpr bool RAGGED_N = true;   // generic element-guarded edge epilogue
     static constexpr int WAVES_M = 2, WAVES_N = 4, FM = 5, FN = 4;
     static constexpr int WAVES = 8, THREADS = 512, BM = 160, BN = 256;
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;

@@ -38,6 +38,7 @@ namespace ivit {
 #endif
 
 struct Tile160x256W4 {
+    static constexpr bool RAGGED_N = true;   // generic element-guarded edge epilogue
     static constexpr int WAVES_M = 2, WAVES_N = 2, FM = 5, FN = 8;
     static constexpr int WAVES = 4, THREADS = 256, BM = 160, BN = 256;
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;

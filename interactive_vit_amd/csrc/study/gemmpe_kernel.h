@@ -35,6 +35,7 @@ namespace ivit {
 #endif
 
 struct TilePE {
+    static constexpr bool RAGGED_N = true;   // generic element-guarded edge epilogue
     static constexpr int BM = 256, BN = 128, WAVES = 8, THREADS = 512;
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
     static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;        // 48 KiB

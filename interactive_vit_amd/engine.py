@@ -28,6 +28,7 @@ ABI_SYMBOLS = (
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
     "ivit_profile_kernel_count", "ivit_profile_kernel_read", "ivit_debug_layer_tap", "ivit_debug_weight_fp8", "ivit_ln_fold_calibrate",
     "ivit_forward_host_async", "ivit_host_wait", "ivit_comm_unique_id", "ivit_comm_init", "ivit_allgather_cls",
+    "ivit_forward_device_packed", "ivit_shard_layout", "ivit_allgather_rows",
 )
 
 
@@ -38,7 +39,7 @@ class IvitConfigC(ctypes.Structure):
                 ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PRECISIONS = {"bf16": 0, "fp8": 1, "f16": 2, "f16x": 3}
 
 
@@ -85,6 +86,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_comm_unique_id.argtypes = [c_p]
         lib.ivit_comm_init.argtypes = [c_p, c_p, c_i, c_i]
         lib.ivit_allgather_cls.argtypes = [c_p, c_p, c_p, c_i64, c_p]
+        lib.ivit_forward_device_packed.argtypes = [c_p, c_i, c_i, c_p, c_p, c_i64, c_p]
+        lib.ivit_shard_layout.argtypes = [c_i64, c_i, c_i, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
+        lib.ivit_allgather_rows.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p]
         lib.ivit_preprocess_host.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_i64, ctypes.POINTER(ctypes.c_uint64)]
         lib.ivit_preprocess.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_p]
         lib.ivit_forward_device.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
@@ -109,6 +113,16 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         if path is None:
             _lib = lib
         return lib
+
+
+def shard_layout(total: int, world: int, rank: int):
+    """(begin, rows, padded_rows) of rank's shard of `total` rows - the engine's own rule (include/ivit.h: ivit_shard_layout; host
+    arithmetic, no GPU), which interactive_vit_amd.sharding.shard_range restates for the torch.distributed path."""
+    lib = load_library()
+    b, r, pz = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    if lib.ivit_shard_layout(int(total), int(world), int(rank), ctypes.byref(b), ctypes.byref(r), ctypes.byref(pz)) != 0:
+        raise ValueError(lib.ivit_last_error().decode("utf-8", "replace"))
+    return b.value, r.value, pz.value
 
 
 class PendingTensor(torch.Tensor):
@@ -418,6 +432,23 @@ class Engine:
                                                 local.numel(), ctypes.c_void_p(st)))
         return out
 
+    def forward_packed(self, x: torch.Tensor, packed: torch.Tensor, batch: int, begin: int, stream: int) -> None:
+        """The multi-GPU step's forward (include/ivit.h: ivit_forward_device_packed): stages [begin, end of model) with row b of `packed`
+        ([batch, >= classes + dim] f32, CUDA) written in place as [logits | class-token features] - no copy kernels before the collective."""
+        assert packed.is_cuda and packed.dtype == torch.float32 and packed.dim() == 2 and packed.stride(1) == 1
+        self._check(self.lib.ivit_forward_device_packed(self._h, begin, batch, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(packed.data_ptr()),
+                                                        packed.stride(0), ctypes.c_void_p(stream)))
+
+    def allgather_rows(self, local: torch.Tensor, total_rows: int, out: torch.Tensor, stream: Optional[int] = None) -> torch.Tensor:
+        """ONE RCCL all-gather of every rank's [rows_local, width] block into out [total_rows, width], image order; ragged shards
+        (total_rows % world != 0) are padded inside the engine (include/ivit.h: ivit_allgather_rows)."""
+        assert local.is_cuda and out.is_cuda and local.dtype == out.dtype == torch.float32 and local.is_contiguous() and out.is_contiguous()
+        assert out.shape[0] == total_rows and out.shape[1] == local.shape[1]
+        st = stream if stream is not None else torch.cuda.current_stream(local.device).cuda_stream
+        self._check(self.lib.ivit_allgather_rows(self._h, ctypes.c_void_p(local.data_ptr()), local.shape[0], local.shape[1], int(total_rows),
+                                                 ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(st)))
+        return out
+
     def ln_fold_for(self, batch: int) -> bool:
         """Does a forward of `batch` images fold the encoder's LayerNorms into the following GEMMs
         (include/ivit.h: ivit_ln_fold)?  What the rounding-aware oracle has to mirror for that call."""
@@ -472,7 +503,8 @@ class Engine:
         """The GEMMs this engine multiplies as hi + lo pairs of f16 values (include/ivit.h: IVIT_PRECISION_F16 / F16X) - what the
         oracle's rounding-aware mode mirrors (oracle/vit_oracle.py: SPLIT_GEMMS)."""
         if self.precision == "f16x":
-            return frozenset({"patch", "head", "proj", "mlp1w", "mlp2w"})
+            extra = {"proj"} if os.environ.get("IVIT_F16X_PROJ", "1") != "0" else set()
+            return frozenset({"patch", "head", "mlp1w", "mlp2w"} | extra)
         if self.precision == "f16" and os.environ.get("IVIT_F16_SPLIT_PATCH_HEAD", "1") != "0":
             return frozenset({"patch", "head"})
         return frozenset()

@@ -162,6 +162,12 @@ class HipBackend:
         # largest |mean| / std the fold is kept for (engine default 0.5); the measured ratio is kept in `ln_fold_ratio`.
         self.ln_fold_ratio = None
         if check_ln_fold and precision != "fp8" and self.engine.ln_fold:
+            if calibration_images is None:
+                # say so - uniform-noise pictures exercise the weights' own statistics, not a deployment's inputs
+                import logging
+                logging.getLogger(__name__).warning(
+                    "%s: LayerNorm-fold guard calibrated on %d seeded SYNTHETIC images (no calibration_images given); pass real sample "
+                    "pictures to HipBackend / build_plugins for a checkpoint whose residual stream depends on its inputs", cfg.name, min(2, max_batch))
             images = calibration_images if calibration_images is not None else synthetic_images(min(2, max_batch), cfg, seed=7)
             if images.dim() == 3:
                 images = images.unsqueeze(0)
@@ -208,8 +214,11 @@ def instances():
     if spec:
         from ..weights import load_state_dict_file
         for item in spec.split(","):
-            name, _, path = item.rpartition("=")
-            name = name or variants[0]
+            # "<variant>=<path>": only a known variant name in front of the FIRST '=' is a name (a path may contain '=')
+            head, sep, tail = item.partition("=")
+            name, path = (head, tail) if (sep and head in VARIANTS) else (variants[0], item)
+            if name not in variants:
+                raise ValueError(f"IVIT_WEIGHTS names variant '{name}', which IVIT_VARIANTS ({','.join(variants)}) does not serve")
             state_dicts[name] = load_state_dict_file(path, VARIANTS[name])
     return build_plugins(ModelBase, PinoutCls, variants, state_dicts=state_dicts,
                          device=int(os.environ.get("IVIT_DEVICE", "0")),

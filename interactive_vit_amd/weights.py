@@ -98,8 +98,15 @@ def load_state_dict_file(path: str, cfg: VitConfig) -> Dict[str, torch.Tensor]:
             raise TypeError(f"{path}: '{name}' has dtype {t.dtype}")
         t = t.detach().to(torch.float32)
         if tuple(t.shape) != tuple(shape):
-            if t.numel() != int(torch.tensor(shape).prod()):
-                raise ValueError(f"{path}: '{name}' has shape {tuple(t.shape)}, expected {tuple(shape)}")
+            # Only the two documented layouts are re-viewed; anything else with the right element count (a transposed
+            # [D, Mlp] mlp.0.weight, a [D, 3D] in_proj) would run and give finite, wrong logits - refuse it by name.
+            got = tuple(t.shape)
+            d, p = cfg.dim, cfg.patch
+            allowed = ((name == "conv_proj.weight" and got == (d, 3 * p * p))
+                       or (name == "encoder.pos_embedding" and got == (cfg.tokens, d))
+                       or (name == "class_token" and got in ((d,), (1, d))))
+            if not allowed:
+                raise ValueError(f"{path}: '{name}' has shape {got}, expected {tuple(shape)}")
             t = t.reshape(shape)
         sd[name] = t.contiguous()
     return sd

@@ -107,9 +107,10 @@ OPERAND_DTYPE = torch.bfloat16
 # test uses) = all of them.
 ROUND_ONLY = None
 
-# The split-operand GEMMs of the f16 data path (include/ivit.h: ivit_split_gemms): these GEMMs multiply hi + lo pairs of
-# f16 values (x = hi + lo to 22 bits) in three MFMA passes with f32 accumulation - an f32-class product.  A set of names
-# out of {"patch", "head", "proj"}; tests / bench set it from Engine.split_gemms.
+# The split-operand GEMMs of the f16 data path (include/ivit.h: IVIT_PRECISION_F16 / F16X): these GEMMs multiply hi + lo pairs of
+# f16 values in two or three MFMA passes with f32 accumulation (x = hi + lo to 22 bits while lo is a normal f16; for |x| < 2^-3
+# lo is subnormal with step 2^-24, i.e. ~19 bits for N(0, 0.02^2)-scale weights).  A set of names out of {"patch", "head", "proj"}
+# (both operands) and {"qkvw", "mlp1w", "mlp2w"} (weights only); tests / bench set it from Engine.split_gemms.
 SPLIT_GEMMS = frozenset()
 
 
@@ -276,10 +277,10 @@ def attention_map(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> to
 LN_FOLD = False
 
 
-# How the engine prepares the folded weight W' = W . diag(gamma) (ivit_fold_ln_weights): "twice" = from its 16-bit copy
-# of W, rounded again (bf16 data path, rounds 1-2); "once" = from the f32 matrix the caller handed to ivit_set_weight,
-# one rounding, and c = W beta + b from the f32 matrix too (f16 data path from round 3 on).  Set by tests / bench from
-# Engine.fold_rounding.
+# How the folded weight W' = W . diag(gamma) is prepared.  "twice" = what the ENGINE does for every non-split matrix
+# (ivit_fold_ln_weights): from its 16-bit copy of W, rounded again.  "once" = from the f32 matrix, one rounding - a STUDY-ONLY
+# switch of tools/f16_error_terms.py (it changes nothing for gamma = 1 and the engine does not implement it; the weight-split
+# matrices of IVIT_PRECISION_F16X are folded from the f32 original, which `wsplit` below mirrors).  No test sets it.
 FOLD_ROUNDING = "twice"
 
 

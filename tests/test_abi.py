@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     exported = set(re.findall(r"\bT (ivit_[a-z_0-9]+)", out))
     assert set(header_symbols()) <= exported
     lib = engine.load_library()
-    assert lib.ivit_abi_version() == engine.ABI_VERSION == 7
+    assert lib.ivit_abi_version() == engine.ABI_VERSION == 8
     assert b"gfx950" in lib.ivit_build_info()
 
 
@@ -115,15 +115,13 @@ def test_missing_library_fails_loudly(tmp_path):
 def test_hot_kernels_keep_their_registers(built_lib):
     """Register / scratch figures from the code objects' own metadata (build.kernel_resources).  No numerical test notices a spill: a
     recompile in round 3 turned the hoisted LDS addresses of the 577-key attention kernel into 52 spilled dwords per lane and doubled
-    ViT-L/16-384's attention time with every parity test green.  Every GEMM / attention kernel of the library must be scratch-free,
-    except the ones listed here with their known epilogue-only spill (bytes per lane)."""
+    ViT-L/16-384's attention time with every parity test green.  Every GEMM / attention kernel of the library must be scratch-free."""
+    pytest.importorskip("msgpack")   # reads the code objects' msgpack metadata notes (not a declared dependency of the product)
     from interactive_vit_amd.build import kernel_resources
     res = kernel_resources(built_lib)
     assert len(res) > 100, "code-object metadata not found"
-    known = {   # classic (run-time epilogue kind) instantiations: the bias / column-scale vectors of the epilogue go to scratch once per tile
-        "ivit_gemm_bf16_256x256x64_stagE": 192, "ivit_gemm_f16_256x256x64_stagE": 192, "ivit_gemm_fp8_256x256x128_stagE": 192,
-        "ivit_gemm_bf16_160x128x64_sbE": 160, "ivit_gemm_f16_160x128x64_sbE": 160, "ivit_gemm_fp8_160x128x128_sbE": 160,
-    }
+    known = {}   # round 4: none.  (Rounds 2-3 carried 160-192 bytes per lane in the classic 256 x 256 and three-per-CU kernels: their
+                 # element-guarded EDGE epilogue; now the f32-output kinds are their own "_f32" instantiations and edge tiles guard whole quads)
     seen = 0
     for name, r in res.items():
         if "ivit_gemm_" not in name and "ivit_attention_bf16" not in name:

@@ -77,6 +77,50 @@ def test_two_rank_gloo_all_gather_reassembles_the_batch(total):
         assert torch.allclose(cls, full["cls"], atol=1e-5)
 
 
+def _layout_worker(rank, world, port, total, width, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from interactive_vit_amd.engine import shard_layout          # the engine's own rule (C ABI, host arithmetic: no GPU needed)
+        begin, rows, big = shard_layout(total, world, rank)
+        full = torch.arange(total * width, dtype=torch.float32).reshape(total, width)
+        local = full[begin:begin + rows]
+        # what ivit_allgather_rows does on the device for ragged shards: pad to the largest shard, ONE all-gather, compact by the layout
+        padded = torch.zeros((big, width))
+        padded[:rows] = local
+        gathered = torch.empty((world * big, width))
+        dist.all_gather_into_tensor(gathered, padded)
+        out = torch.empty((total, width))
+        for r in range(world):
+            b, n, _ = shard_layout(total, world, r)
+            out[b:b + n] = gathered[r * big:r * big + n]
+        q.put((rank, begin, rows, big, bool(torch.equal(out, full))))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [6, 5, 1])     # equal shards; ragged (3 + 2); a rank with no rows (1 + 0)
+def test_engine_shard_layout_and_padding_rule_two_ranks(total):
+    """The engine-side padding rule of ivit_allgather_rows (include/ivit.h) restated with gloo on two ranks: ivit_shard_layout gives the
+    same shards as sharding.shard_range, and pad -> one all-gather -> compact reassembles the batch in image order on every rank."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_layout_worker, args=(r, world, port, total, 7, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, begin, rows, big, ok in results:
+        assert (begin, begin + rows) == shard_range(total, rank, world)
+        assert big == max(shard_sizes(total, world)) and ok
+
+
 def test_bench_gpus_n_starts_its_own_ranks():
     """`python bench.py --gpus N` must work un-wrapped (the driver's plain invocation): before touching the GPU it
     starts torch.distributed.run as a CHILD and relays the result line.  Without a GPU every rank stops with the

@@ -246,28 +246,36 @@ def test_config2_vit_b16_batch64_as_dispatched():
     """BASELINE configs[1] (the bench default): LayerNorm folded, 160x128 tiles for proj / MLP, 256x256 for QKV."""
     run_config("vit_b_16", 64, "bf16",
                {"qkv": "ivit_gemm_bf16_256x256x64_stag_lf", "proj": "ivit_gemm_bf16_160x128x64_rs",
-                "mlp1": "ivit_gemm_bf16_160x128x64_sb_lf", "mlp2": "ivit_gemm_bf16_160x128x64"},   # a layer run alone: no next layer to leave statistics for
+                "mlp1": "ivit_gemm_bf16_160x128x64_sb_lf", "mlp2": "ivit_gemm_bf16_160x128x64_f32"},   # a layer run alone: no next layer to leave statistics for
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
 
 def test_config3_vit_l16_384_batch128_as_dispatched():
     """BASELINE configs[2]: 73 856 token rows - every encoder GEMM on the staggered 256x256 tile with the classic
     epilogues, LayerNorm as a kernel, attention over 577 keys."""
-    k = "ivit_gemm_bf16_256x256x64_stag"
-    run_config("vit_l_16_384", 128, "bf16", {"qkv": k, "proj": k, "mlp1": k, "mlp2": k},
+    k = "ivit_gemm_bf16_256x256x64_stag"     # "_f32": the f32-output epilogues (residual add) are their own instantiations since round 4
+    run_config("vit_l_16_384", 128, "bf16", {"qkv": k, "proj": k + "_f32", "mlp1": k, "mlp2": k + "_f32"},
                expect_fold=False, layers_to_check=(0, 23), layer_tol=1e-3)
+
+
+def test_config4_vit_b16_batch256_as_dispatched():
+    """BASELINE configs[3]'s shard (ViT-B/16 B = 2048 over 8 GPUs = 256 images per GPU, 50 432 token rows): the dispatch flips to the
+    256 x 256 tile on every encoder GEMM and to LayerNorm kernels (gemm_prefers_256) - gated per GEMM at that batch (VERDICT r3 #3)."""
+    k = "ivit_gemm_bf16_256x256x64_stag"
+    run_config("vit_b_16", 256, "bf16", {"qkv": k, "proj": k + "_f32", "mlp1": k, "mlp2": k + "_f32"},
+               expect_fold=False, layers_to_check=(0, 11), layer_tol=1e-3)
 
 
 def test_config5_vit_h14_batch256_bf16_as_dispatched():
     k = "ivit_gemm_bf16_256x256x64_stag"
-    run_config("vit_h_14", 256, "bf16", {"qkv": k, "proj": k, "mlp1": k, "mlp2": k},
+    run_config("vit_h_14", 256, "bf16", {"qkv": k, "proj": k + "_f32", "mlp1": k, "mlp2": k + "_f32"},
                expect_fold=False, layers_to_check=(0, 31), layer_tol=1.3e-3)   # measured 1.02e-3 (five chained roundings, K = 1280 / 5120); every step alone is gated above
 
 
 def test_config5_vit_h14_batch256_fp8_as_dispatched():
     """BASELINE configs[4]: e4m3 weights + activations on the 2x-rate scaled MFMA, 256x256x128 tile."""
     k = "ivit_gemm_fp8_256x256x128_stag"
-    run_config("vit_h_14", 256, "fp8", {"qkv": k, "proj": k, "mlp1": k, "mlp2": k},
+    run_config("vit_h_14", 256, "fp8", {"qkv": k, "proj": k + "_f32", "mlp1": k, "mlp2": k + "_f32"},
                expect_fold=False, layers_to_check=(0, 31), layer_tol=3e-2)     # whole layer: five chained quantisations on a 2^-4 grid; the per-step gates above are the strict ones
 
 
@@ -398,7 +406,7 @@ def test_config2_vit_b16_batch64_f16_as_dispatched():
     identical operand bytes (one unit of f16 = 2^-11: eight times finer than the bf16 gate)."""
     run_config("vit_b_16", 64, "f16",
                {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs",
-                "mlp1": "ivit_gemm_f16_160x128x64_sb_lf", "mlp2": "ivit_gemm_f16_160x128x64"},
+                "mlp1": "ivit_gemm_f16_160x128x64_sb_lf", "mlp2": "ivit_gemm_f16_160x128x64_f32"},
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
 
@@ -407,5 +415,5 @@ def test_config2_vit_b16_batch64_f16x_as_dispatched():
     pairs - every step gated on the engine's own operand bytes (the attention tap carries [hi | lo])."""
     run_config("vit_b_16", 64, "f16x",
                {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs",
-                "mlp1": "ivit_gemm_f16_160x128x64_sb_lf", "mlp2": "ivit_gemm_f16_160x128x64"},
+                "mlp1": "ivit_gemm_f16_160x128x64_sb_lf", "mlp2": "ivit_gemm_f16_160x128x64_f32"},
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)

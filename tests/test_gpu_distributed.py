@@ -29,7 +29,7 @@ def test_bench_runs_under_torchrun_with_rccl():
     assert len(out_lines) == 1, out_lines          # RCCL's banner etc. must not reach stdout: ONE line, the result
     d = json.loads(out_lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["collective"] == "ncclAllGather issued by the engine (ivit_allgather_cls, RCCL), 1 per step"
+    assert d["config"]["collective"].startswith("ncclAllGather issued by the engine (ivit_allgather_rows, RCCL)")
     assert d["parity"]["gathered_equals_local"] is True
 
 
@@ -90,3 +90,41 @@ def test_bench_gpus_n_is_launched_by_bench_itself():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_packed_forward_writes_the_collective_block_in_place():
+    """the multi-GPU step is forward + ONE ncclAllGather.  ivit_forward_device_packed lets the head GEMM and the final
+    LayerNorm store [logits | class-token features] with the packed block's row stride: bit-identical to the two dense outputs,
+    nothing outside the block's columns touched; ivit_allgather_rows on a communicator of one rank hands the block back unchanged."""
+    import torch
+    from interactive_vit_amd.engine import Engine
+    from interactive_vit_amd.vit_config import test_config as small_config
+    from interactive_vit_amd.weights import init_weights, synthetic_images
+    cfg = small_config()
+    sd = init_weights(cfg, seed=3, mode="rich")
+    eng = Engine(cfg, sd, device=0, max_batch=5)
+    try:
+        b = 5
+        x = synthetic_images(b, cfg, seed=17).cuda()
+        ns = len(eng.stages)
+        stream = torch.cuda.current_stream().cuda_stream
+        logits = torch.empty((b, cfg.classes), dtype=torch.float32, device="cuda")
+        clsf = torch.empty((b, cfg.dim), dtype=torch.float32, device="cuda")
+        eng.forward_into(x, logits, clsf, b, 0, ns, stream)
+        width = cfg.classes + cfg.dim
+        packed = torch.full((b, width + 8), -7.0, dtype=torch.float32, device="cuda")     # a stride wider than the block
+        eng.forward_packed(x, packed, b, 0, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(packed[:, :cfg.classes], logits) and torch.equal(packed[:, cfg.classes:width], clsf)
+        assert bool((packed[:, width:] == -7.0).all())
+        tight = torch.empty((b, width), dtype=torch.float32, device="cuda")
+        eng.forward_packed(x, tight, b, 0, stream)
+        eng.comm_init(0, 1, lambda ident: ident)
+        out = torch.zeros((b, width), dtype=torch.float32, device="cuda")
+        eng.allgather_rows(tight, b, out, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:, :cfg.classes], logits) and torch.equal(out[:, cfg.classes:], clsf)
+        with pytest.raises(Exception, match="row_stride"):
+            eng.forward_packed(x, torch.empty((b, width - 4), dtype=torch.float32, device="cuda"), b, 0, stream)
+    finally:
+        eng.close()

@@ -205,6 +205,18 @@ def test_checkpoint_file_in_torchvision_names_loads(tmp_path):
     save_file(broken, path)
     with pytest.raises(ValueError, match="encoder.ln.weight"):
         load_state_dict_file(path, cfg)
+    # same element count, wrong layout: a transposed matrix is refused by name, not silently re-viewed
+    for key in ("encoder.layers.encoder_layer_0.mlp.0.weight", "encoder.layers.encoder_layer_1.self_attention.in_proj_weight"):
+        broken = dict(stored); broken[key] = stored[key].t().contiguous()
+        save_file(broken, path)
+        with pytest.raises(ValueError, match=key.replace(".", r"\.")):
+            load_state_dict_file(path, cfg)
+    # the documented position-embedding / class-token layouts are accepted
+    ok = dict(stored); ok["encoder.pos_embedding"] = stored["encoder.pos_embedding"].reshape(cfg.tokens, cfg.dim).contiguous()
+    ok["class_token"] = stored["class_token"].reshape(cfg.dim).contiguous()
+    save_file(ok, path)
+    got3 = load_state_dict_file(path, cfg)
+    assert tuple(got3["encoder.pos_embedding"].shape) == (1, cfg.tokens, cfg.dim) and tuple(got3["class_token"].shape) == (1, 1, cfg.dim)
 
 
 def test_category_labels_come_from_a_local_file(tmp_path, monkeypatch):
