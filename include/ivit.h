@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define IVIT_ABI_VERSION 8
+#define IVIT_ABI_VERSION 9
 
 #define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
 #define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
@@ -59,6 +59,10 @@ extern "C" {
                                    (tests/test_gpu_parity.py: test_split_weight_low_parts_survive).
                                    Both f16 modes run the patch embedding and the classifier head on hi + lo pairs of both operands (0.7 % of the FLOPs) */
 
+#define IVIT_PRECISION_FP8M 4   /* e4m3 on the MLP pair only (round 4: the configuration the fp8 error budget names, profiles/r03_fp8_error_terms.txt): MLP up /
+                                   down - 53 % of the FLOPs - on the 2x-rate scaled MFMA with the scales of IVIT_PRECISION_FP8 (ivit_fp8_calibrate); QKV,
+                                   attention and out-projection stay bf16 (LayerNorm kernels) */
+
 typedef struct ivit_engine ivit_engine;
 
 typedef struct ivit_config {
@@ -72,7 +76,7 @@ typedef struct ivit_config {
     float   ln_eps;
     int32_t device;     /* HIP device ordinal */
     int32_t max_batch;  /* workspaces are sized for this many images per call */
-    int32_t precision;  /* IVIT_PRECISION_* */
+    int32_t precision;  /* IVIT_PRECISION_* (BF16, FP8, F16, F16X, FP8M) */
 } ivit_config;
 
 /* ABI / build introspection (no GPU needed). */
@@ -172,6 +176,13 @@ int ivit_forward_device(ivit_engine* e, int stage_begin, int stage_end, int batc
 int ivit_attention_map(ivit_engine* e, int layer, int batch, const void* in, void* out, void* stream);
 /* host-buffer form of the same (CPU f32 in / out; out_capacity in floats) */
 int ivit_attention_map_host(ivit_engine* e, int layer, int batch, const float* in, float* out, int64_t out_capacity);
+
+/* The layer node with its attention map as a SECOND output channel (Response ships every channel of every node,
+ * main/message.py:80-83; io() is the operator's to override, main/context.py:94-96): `out` = the residual-inclusive block as
+ * ivit_forward_device(stage 3 + layer) gives it, `attn` = f32 [B, heads, N, N] from the q|k|v tensor that same call computed - bit for
+ * bit the map of the `.attn` inspector node, without its second LayerNorm + QKV GEMM.  Backs `<model>:encoder.layers.<i>.with_attn`. */
+int ivit_layer_with_attn(ivit_engine* e, int layer, int batch, const void* in, void* out, void* attn, void* stream);
+int ivit_layer_with_attn_host(ivit_engine* e, int layer, int batch, const float* in, float* out, int64_t out_capacity, float* attn, int64_t attn_capacity);
 
 /* fp8 data path (IVIT_PRECISION_FP8).  Policy (the reference has none - stated in DESIGN.md): OCP e4m3fn,
  * saturating; weights quantised per OUTPUT ROW (scale = row amax / 448) from their bf16 copies;

@@ -102,10 +102,14 @@ static bool config_ok(const ivit_config* c, std::string* why) {
     if (c->mlp <= 0 || c->mlp % 64) return bad("mlp must be a positive multiple of 64");
     if (c->layers < 0 || c->classes <= 0 || c->max_batch <= 0) return bad("layers/classes/max_batch out of range");
     if (c->dim > 2048) return bad("dim > 2048 unsupported");
-    if (c->precision != IVIT_PRECISION_BF16 && c->precision != IVIT_PRECISION_FP8 && c->precision != IVIT_PRECISION_F16 && c->precision != IVIT_PRECISION_F16X)
-        return bad("precision must be IVIT_PRECISION_BF16, IVIT_PRECISION_F16, IVIT_PRECISION_F16X or IVIT_PRECISION_FP8");
+    if (c->precision != IVIT_PRECISION_BF16 && c->precision != IVIT_PRECISION_FP8 && c->precision != IVIT_PRECISION_F16 && c->precision != IVIT_PRECISION_F16X &&
+        c->precision != IVIT_PRECISION_FP8M)
+        return bad("precision must be IVIT_PRECISION_BF16, IVIT_PRECISION_F16, IVIT_PRECISION_F16X, IVIT_PRECISION_FP8 or IVIT_PRECISION_FP8M");
     return true;
 }
+
+// the e4m3 data paths: IVIT_PRECISION_FP8 (all four encoder GEMMs) and IVIT_PRECISION_FP8M (the MLP pair only)
+static inline bool precision_is_fp8(int precision) { return precision == IVIT_PRECISION_FP8 || precision == IVIT_PRECISION_FP8M; }
 
 extern "C" int ivit_stage_count(const ivit_config* cfg) { return cfg ? 6 + cfg->layers : -1; }
 
@@ -382,7 +386,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         const char* gr = getenv("IVIT_GRAPHS");
         e->graphs_on = !(gr && atoi(gr) == 0);
         const char* fl = getenv("IVIT_FOLD_LN");
-        e->fold_ln = !(fl && atoi(fl) == 0) && cfg->precision != IVIT_PRECISION_FP8 && cfg->dim <= 64 * GEMM_LN_SLOTS;
+        e->fold_ln = !(fl && atoi(fl) == 0) && !precision_is_fp8(cfg->precision) && cfg->dim <= 64 * GEMM_LN_SLOTS;
         e->fold_always = fl && atoi(fl) == 2;
         if (e->split < 1 || e->split > ivit_engine::MAX_SPLIT) e->split = 1;
         for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
@@ -428,7 +432,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     chk(dev_alloc(e, (void**)&e->u, (size_t)rows_tok * Mlp * 2, true));
     chk(dev_alloc(e, (void**)&e->hc, (size_t)(round_up(B, 256) + 256) * e->ld_hc * 2, true));
     chk(dev_alloc(e, (void**)&e->ln_part, (size_t)rows_tok * GEMM_LN_SLOTS * sizeof(float2), true));
-    if (cfg->precision == IVIT_PRECISION_FP8) {
+    if (precision_is_fp8(cfg->precision)) {
         e->ld8d = round_up(D, 128); e->ld8m = round_up(Mlp, 128);
         chk(dev_alloc(e, (void**)&e->h8, (size_t)rows_tok * e->ld8d, true));
         chk(dev_alloc(e, (void**)&e->att8, (size_t)rows_tok * e->ld8d, true));
@@ -696,6 +700,29 @@ static int run_layer_fp8(ivit_engine* e, const Ws& w, hipStream_t st, int li, in
     return 0;
 }
 
+// IVIT_PRECISION_FP8M (round 4; DESIGN.md section 3b's own conclusion): e4m3 only where it buys the most for the least error - MLP up / down
+// (53 % of the FLOPs, on the 2x-rate scaled MFMA; operands LN2 output and GELU output with static per-tensor scales, per-row weight
+// scales as IVIT_PRECISION_FP8); QKV projection, attention and out-projection stay on the bf16 data path with LayerNorm kernels.
+static int run_layer_fp8m(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B, int tap = TAP_NONE, const float* xi = nullptr, float* xo = nullptr) {
+    const int D = e->D, M = B * e->N;
+    LayerWeights& lw = e->layers[li];
+    if (!xi) xi = w.x;
+    if (!xo) xo = w.x;
+    if (run_layernorm(e, st, xi, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
+    if (tap == TAP_H1) return 0;
+    if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "qkv")) return 1;
+    if (tap == TAP_QKV) return 0;
+    if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
+    if (tap == TAP_ATT) return 0;
+    if (run_gemm(e, st, w.att, e->ld_att, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, xi, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
+    if (tap == TAP_PROJ) return 0;
+    if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, nullptr, nullptr, w.h8, 1.0f / lw.s_h2)) return 1;
+    if (tap == TAP_H2) return 0;
+    if (run_gemm_fp8(e, st, w.h8, e->ld8d, lw.q1, M, lw.b1, EPI_BIAS_GELU_FP8, w.u8, e->ld8m, nullptr, 0, 1.0f / lw.s_u, "mlp1")) return 1;
+    if (tap == TAP_U) return 0;
+    return run_gemm_fp8(e, st, w.u8, e->ld8m, lw.q2, M, lw.b2, EPI_BIAS_RESID_F32, xo, D, w.x, D, 1.0f, "mlp2");
+}
+
 // The LayerNorm fold pays where the residual GEMMs run two workgroups per CU (their longer epilogue hides behind
 // the other workgroup's main loop: ViT-B/16 +3.5 %); where they take the 256x256 tile (ViT-L / ViT-H batches, one
 // workgroup per CU) the exposed epilogue costs more than the LayerNorm kernels it saves (-1...-2 %), so those calls
@@ -733,9 +760,9 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "mlp1")) return 1;
         return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, xo, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2");
     }
-    if (!amax4 && e->cfg.precision == IVIT_PRECISION_FP8) {
+    if (!amax4 && precision_is_fp8(e->cfg.precision)) {
         if (!e->fp8_ready) return fail("fp8 engine is not calibrated: call ivit_fp8_calibrate first");
-        return run_layer_fp8(e, w, st, li, B, tap, xi, xo);
+        return e->cfg.precision == IVIT_PRECISION_FP8M ? run_layer_fp8m(e, w, st, li, B, tap, xi, xo) : run_layer_fp8(e, w, st, li, B, tap, xi, xo);
     }
     if (!amax4 && fold_for_rows(e, M)) {
         LnFold fold; fold.part = w.ln_part; fold.xb = w.h;
@@ -823,7 +850,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         // the position embedding; a small kernel writes the class rows.  In front of a LayerNorm-folded first layer the same epilogue
         // also leaves the statistics pairs and the 16-bit copy of the token rows (round 3: ivit_row_stats_pairs then only visits the
         // B class rows instead of re-reading the whole stream: 15.7 us -> 2 us at ViT-B/16 B = 64)
-        stats_from_patch = end > ST_LAYER0 && e->cfg.layers > 0 && !e->ratio_on && e->cfg.precision != IVIT_PRECISION_FP8 && fold_for_rows(e, B * N);
+        stats_from_patch = end > ST_LAYER0 && e->cfg.layers > 0 && !e->ratio_on && !precision_is_fp8(e->cfg.precision) && fold_for_rows(e, B * N);
         LnFold pfold; pfold.part = w.ln_part; pfold.xb = w.h;
         if (run_gemm(e, st, w.patches, e->ld_patch, e->w_patch, B * Np, e->b_patch, stats_from_patch ? EPI_BIAS_ROWADD_STATS : EPI_BIAS_ROWADD_F32,
                      (end == ST_TOKENS + 1) ? out : w.x, D, nullptr, 0, e->pos, D, Np, N, 1, stats_from_patch ? &pfold : nullptr, "patch")) return 1;
@@ -1027,7 +1054,7 @@ static int forward_host_impl(ivit_engine* e, int stage_begin, int stage_end, int
     const int L = e->cfg.layers;
     const bool begins_on_layer = stage_begin >= ST_LAYER0 && stage_begin < ST_LAYER0 + L;
     const bool ends_on_layer = stage_end - 1 >= ST_LAYER0 && stage_end - 1 < ST_LAYER0 + L;
-    const bool folds = e->cfg.precision != IVIT_PRECISION_FP8 && fold_for_rows(e, batch * e->N);
+    const bool folds = !precision_is_fp8(e->cfg.precision) && fold_for_rows(e, batch * e->N);
     // the previous host call ended on an encoder layer and left its output's statistics pairs and 16-bit copy in the workspace
     // (nothing has touched them since: ws_acquire clears the token), and that output is this call's input: skip ivit_row_stats_pairs
     const bool chained_stats = in_token != 0 && in_token == e->resident_token && n_in == e->resident_elems &&
@@ -1130,21 +1157,77 @@ extern "C" int ivit_host_wait(ivit_engine* e, uint64_t ticket) {
 }
 
 // caller holds e->mu and has set the device
-static int attention_map_locked(ivit_engine* e, int layer, int B, const float* in, float* out, hipStream_t st) {
-    if (require_weights(e)) return 1;
-    const int D = e->D, M = B * e->N;
-    LayerWeights& lw = e->layers[layer];
-    const Ws w = ws_slice(e, 0);
-    if (run_layernorm(e, st, in, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
-    if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D)) return 1;
+// softmax(q k^T / sqrt(dh)) of the q|k|v tensor that is in the workspace -> f32 [B, heads, N, N]
+static int attention_probs(ivit_engine* e, const Ws& w, int B, float* out, hipStream_t st) {
     AttnParams ap{};
-    ap.qkv = w.qkv; ap.ldqkv = 3 * D; ap.out = w.att; ap.ldo = e->ld_att;
+    ap.qkv = w.qkv; ap.ldqkv = 3 * e->D; ap.out = w.att; ap.ldo = e->ld_att;
     ap.batch = B; ap.tokens = e->N; ap.heads = e->cfg.heads; ap.head_dim = e->dh; ap.f16 = e->f16;
     ap.scale = 1.0f / std::sqrt((float)e->dh);
     ap.probs = out;
     ap.out8 = nullptr; ap.ldo8 = 0; ap.scale8 = 1.0f;
     ProfScope ps(e, PC_ATTN, st, 2.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh, 0.0);
     HIP_TRY(launch_attention(ap, st));
+    return 0;
+}
+
+// The inspector node: the FRONT of the layer exactly as a layer call of this batch runs it (LayerNorm folded into the QKV GEMM or a
+// LayerNorm kernel, the data path's precision), then the probabilities - so the map is bit for bit what the layer itself attends with
+// (round 4; it used to be the unfolded bf16 form whatever the layer did).
+static int attention_map_locked(ivit_engine* e, int layer, int B, const float* in, float* out, hipStream_t st) {
+    if (require_weights(e)) return 1;
+    const Ws w = ws_slice(e, 0);
+    if (run_layer(e, w, st, layer, B, nullptr, false, false, TAP_QKV, in, nullptr)) return 1;
+    return attention_probs(e, w, B, out, st);
+}
+
+// The layer node with its attention map as a second output channel (SURVEY 8(f) row 4 as written): one layer call, then the
+// probabilities from the q|k|v tensor THAT call left in the workspace - no second LayerNorm / QKV GEMM.
+static int layer_with_attn_locked(ivit_engine* e, int layer, int B, const float* in, float* out, float* attn, hipStream_t st) {
+    if (require_weights(e)) return 1;
+    const Ws w = ws_slice(e, 0);
+    if (run_layer(e, w, st, layer, B, nullptr, false, false, TAP_NONE, in, out)) return 1;
+    return attention_probs(e, w, B, attn, st);
+}
+
+extern "C" int ivit_layer_with_attn(ivit_engine* e, int layer, int batch, const void* in, void* out, void* attn, void* stream) {
+    if (!e || !in || !out || !attn) return fail("ivit_layer_with_attn: null argument");
+    if (layer < 0 || layer >= e->cfg.layers) return fail("layer %d outside 0..%d", layer, e->cfg.layers - 1);
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
+    const int rc = layer_with_attn_locked(e, layer, batch, (const float*)in, (float*)out, (float*)attn, st);
+    if (ws.release()) return 1;
+    return rc;
+}
+
+extern "C" int ivit_layer_with_attn_host(ivit_engine* e, int layer, int batch, const float* in, float* out, int64_t out_capacity, float* attn, int64_t attn_capacity) {
+    if (!e || !in || !out || !attn) return fail("ivit_layer_with_attn_host: null argument");
+    if (layer < 0 || layer >= e->cfg.layers) return fail("layer %d outside 0..%d", layer, e->cfg.layers - 1);
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
+    const int64_t n_x = (int64_t)batch * e->N * e->D, n_map = (int64_t)batch * e->cfg.heads * e->N * e->N;
+    if (n_x > out_capacity || n_map > attn_capacity) return fail("ivit_layer_with_attn_host: outputs need %lld and %lld floats", (long long)n_x, (long long)n_map);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->own_stream;
+    const size_t need = (size_t)n_map * 4;
+    if (need > e->map_bytes) {
+        if (e->map_buf) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(e->map_buf); e->map_buf = nullptr; e->map_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&e->map_buf, need));
+        e->map_bytes = need;
+    }
+    WsScope ws(e, st);
+    if (ws.acquire()) return 1;
+    if (ext_buffer_writable(e, e->ext_in, st) || ext_buffer_writable(e, e->ext_out, st)) return 1;
+    e->resident_token = 0;   // the ext buffers are overwritten outside the chained-call bookkeeping
+    HIP_TRY(hipMemcpyAsync(e->ext_in, in, (size_t)n_x * 4, hipMemcpyHostToDevice, st));
+    if (layer_with_attn_locked(e, layer, batch, e->ext_in, e->ext_out, e->map_buf, st)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, e->ext_out, (size_t)n_x * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(attn, e->map_buf, need, hipMemcpyDeviceToHost, st));
+    if (ws.release()) return 1;
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -1239,7 +1322,7 @@ extern "C" int ivit_preprocess_host(ivit_engine* e, int batch, const float* in, 
 
 extern "C" int ivit_fp8_calibrate(ivit_engine* e, int batch, const void* in, void* stream) {
     if (!e || !in) return fail("ivit_fp8_calibrate: null argument");
-    if (e->cfg.precision != IVIT_PRECISION_FP8) return fail("ivit_fp8_calibrate: engine was created with IVIT_PRECISION_BF16");
+    if (!precision_is_fp8(e->cfg.precision)) return fail("ivit_fp8_calibrate: engine was not created with IVIT_PRECISION_FP8 / IVIT_PRECISION_FP8M");
     if (batch <= 0 || batch > e->cfg.max_batch) return fail("batch %d outside 1..%d (max_batch of this engine)", batch, e->cfg.max_batch);
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
@@ -1351,14 +1434,16 @@ extern "C" int ivit_debug_layer_tap(ivit_engine* e, int layer, int batch, const 
     if (require_weights(e)) return 1;
     hipStream_t st = (hipStream_t)stream;
     const int D = e->D, M = batch * e->N, Mlp = e->cfg.mlp;
-    const bool f8 = e->cfg.precision == IVIT_PRECISION_FP8;
+    const bool f8m = precision_is_fp8(e->cfg.precision);                 // the MLP half stores e4m3
+    const bool f8 = e->cfg.precision == IVIT_PRECISION_FP8;             // ... and so does the attention half
     const Ws w = ws_slice(e, 0);
     const void* src = nullptr; int64_t rb = 0; int eb = 0;
     switch (tap) {
-        case TAP_H1: case TAP_H2: src = f8 ? (const void*)w.h8 : (const void*)w.h; eb = f8 ? 1 : 2; rb = f8 ? e->ld8d : 2 * D; break;
+        case TAP_H1: src = f8 ? (const void*)w.h8 : (const void*)w.h; eb = f8 ? 1 : 2; rb = f8 ? e->ld8d : 2 * D; break;
+        case TAP_H2: src = f8m ? (const void*)w.h8 : (const void*)w.h; eb = f8m ? 1 : 2; rb = f8m ? e->ld8d : 2 * D; break;
         case TAP_QKV: src = w.qkv; eb = 2; rb = 2 * 3 * D; break;
         case TAP_ATT: src = f8 ? (const void*)w.att8 : (const void*)w.att; eb = f8 ? 1 : 2; rb = f8 ? e->ld8d : 2 * e->ld_att; break;   // F16X: [hi | lo] per row
-        case TAP_U: src = f8 ? (const void*)w.u8 : (const void*)w.u; eb = f8 ? 1 : 2; rb = f8 ? e->ld8m : 2 * Mlp; break;
+        case TAP_U: src = f8m ? (const void*)w.u8 : (const void*)w.u; eb = f8m ? 1 : 2; rb = f8m ? e->ld8m : 2 * Mlp; break;
         default: src = w.x; eb = 4; rb = 4 * D; break;   // TAP_PROJ, TAP_OUT: the f32 residual stream
     }
     if ((int64_t)M * rb > out_capacity_bytes) return fail("ivit_debug_layer_tap: output needs %lld bytes, capacity is %lld", (long long)M * rb, (long long)out_capacity_bytes);
@@ -1375,7 +1460,7 @@ extern "C" int ivit_debug_layer_tap(ivit_engine* e, int layer, int batch, const 
 extern "C" int ivit_debug_weight_fp8(ivit_engine* e, int layer, int which, void* out_bytes, int64_t out_capacity_bytes, float* out_rowscale,
                                      int rowscale_capacity, int* rows, int* cols, int* ld) {
     if (!e || !out_bytes || !out_rowscale) return fail("ivit_debug_weight_fp8: null argument");
-    if (e->cfg.precision != IVIT_PRECISION_FP8) return fail("ivit_debug_weight_fp8: engine was created without IVIT_PRECISION_FP8");
+    if (!precision_is_fp8(e->cfg.precision)) return fail("ivit_debug_weight_fp8: engine was created without IVIT_PRECISION_FP8 / IVIT_PRECISION_FP8M");
     if (layer < 0 || layer >= e->cfg.layers || which < 0 || which > 3) return fail("ivit_debug_weight_fp8: layer %d / matrix %d out of range", layer, which);
     std::lock_guard<std::mutex> lk(e->mu);
     if (!e->fp8_ready) return fail("fp8 engine is not calibrated: call ivit_fp8_calibrate first");

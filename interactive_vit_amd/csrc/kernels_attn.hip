@@ -85,9 +85,11 @@ __device__ __forceinline__ void att_stage(char* lds, const bf16_t* src0, int ld,
 // One 16-query block of one (image, head): S^T = K Q^T from the LDS image of K, single exact softmax pass in registers, O^T = V^T P^T with
 // V consumed row-major through ds_read_tr16_b64, normalise, store.  Shared by the one-head and the pipelined multi-head kernel.
 // OP: the 16-bit type of q|k|v, of the softmax numerators fed to P.V and of the output (OpBf16 / OpF16, common.h)
+// wait_v (wave-uniform; true for a wave's FIRST block in the one-head kernel): the V image may still be in flight - K was waited for alone
+// so that Q.K^T and the softmax of the first block run under V's half of the staging burst; drain and publish it before the first P.V.
 template <int DH, int NKF, bool ODD, bool PROBS, class OP>
 __device__ __forceinline__ void att_block(const AttnParams& p, const char* k_lds, const char* v_lds, const bf16x8 (&qf)[AttLayout<DH, NKF, ODD>::KSTEPS],
-                                          int qbase, int b, int h, size_t row0, int N, int fr, int g, float cexp) {
+                                          int qbase, int b, int h, size_t row0, int N, int fr, int g, float cexp, bool wait_v = false) {
     using L = AttLayout<DH, NKF, ODD>;
     constexpr int ATT_DH = DH;
     const bf16x8 zero_frag = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -136,6 +138,10 @@ __device__ __forceinline__ void att_block(const AttnParams& p, const char* k_lds
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
 
+    if (wait_v) {   // every wave of the workgroup passes here exactly once (its first block)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     if (PROBS) {   // lane holds P[q = qbase + fr][key = 16 f + 4 g + j]: a float4 per fragment
         const int q = qbase + fr;
         if (q < N) {
@@ -239,39 +245,49 @@ __global__ __launch_bounds__(512) void ivit_attention_bf16(AttnParams p) {
     constexpr int hs = ATT_DH;
     const int ws = D;
 #endif
-    att_stage<L>(k_lds, qkv + row0 * ld + h * hs + ws, ld, N, L::K_SWZ, wave, nwaves, lane);
-    att_stage<L>(v_lds, qkv + row0 * ld + h * hs + 2 * ws, ld, N, L::V_SWZ, wave, nwaves, lane);
-
-    // ---- Q fragments of the wave's first query block, behind the DMA queue so that their latency
-    // overlaps the staging (B operand: lane holds Q[q + fr][kk*32 + 8g .. +7])
+    // Issue order (round 4): Q fragments of the wave's first block (B operand: lane holds Q[q + fr][kk*32 + 8g .. +7]) and the K image;
+    // wait for both; THEN the V image, and the barrier that publishes K.  The first block's Q.K^T and softmax run while the V half of the
+    // staging burst is still arriving (all workgroups of a launch stage at once: 58 MB at ViT-B/16 B = 64 before anyone computes);
+    // att_block drains and publishes V before its first P.V (wait_v).  The Q registers are "used" by an empty asm right behind the wait:
+    // hipcc waits for a pending register load at its first use with vmcnt(0) when it cannot count what was issued since (the staging
+    // loops) - left to the first MFMA that would also have waited for V and for the next block's Q prefetch.
     const bf16x8 zero_frag = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 qf[L::KSTEPS];
-    {
-        const int qrow = min(q0 + fr, N - 1);
+    auto load_q = [&](int qbase, bf16x8 (&q)[L::KSTEPS]) {
+        const int qrow = min(qbase + fr, N - 1);
 #pragma unroll
         for (int kk = 0; kk < L::KSTEPS; ++kk)
-            qf[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
-                         ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * hs + kk * 32 + g * 8) : zero_frag;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed; the barrier publishes everyone's
-    __syncthreads();
+            q[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
+                        ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * hs + kk * 32 + g * 8) : zero_frag;
+    };
+    load_q(q0, qf);
+    att_stage<L>(k_lds, qkv + row0 * ld + h * hs + ws, ld, N, L::K_SWZ, wave, nwaves, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's K pieces and Q fragments have landed
+#pragma unroll
+    for (int kk = 0; kk < L::KSTEPS; ++kk) asm volatile("" ::"v"(qf[kk]));
+    att_stage<L>(v_lds, qkv + row0 * ld + h * hs + 2 * ws, ld, N, L::V_SWZ, wave, nwaves, lane);
+    constexpr bool split_wait = !PROBS;
+    if (!split_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero rows this wave wrote
+    __builtin_amdgcn_s_barrier();                          // publishes K (and V when it was waited for); a raw barrier: __syncthreads() would drain vmcnt
     const float cexp = p.scale * 1.44269504088896340736f;  // exp(x*scale) = exp2(x*scale*log2 e)
 
     // The wave's 16-query blocks (wave, wave + nwaves, ...) run one after the other, so only one block's
     // scores (NKF x 4 registers) are live at a time: < 128 VGPRs at 197 keys, i.e. two workgroups per
     // CU and one's staging overlaps the other's math.  (K / V fragments are re-read per block: LDS has room.)
+    // (round 4: the NEXT block's Q fragments are loaded before the current block is computed - the plain load at the top of a block
+    // exposed a full memory latency per block, 4-5 times per wave at 577 keys)
+    bf16x8 qn[L::KSTEPS];
 #pragma unroll 1
     for (int blk = wave; blk < nblocks; blk += nwaves) {
         const int qbase = blk * 16;
         asm volatile("" ::: "memory");   // keeps the (block-invariant) K / V fragment reads inside the loop: hoisted, they cost 100+ VGPRs
-        if (blk != wave) {   // later blocks: plain load (the first block's fragments were prefetched above)
-            const int qrow = min(qbase + fr, N - 1);
+        if (blk != wave) {
 #pragma unroll
-            for (int kk = 0; kk < L::KSTEPS; ++kk)
-                qf[kk] = (kk * 32 + g * 8 + 8 <= ATT_DH)
-                             ? *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * hs + kk * 32 + g * 8) : zero_frag;
+            for (int kk = 0; kk < L::KSTEPS; ++kk) qf[kk] = qn[kk];
         }
-        att_block<DH, NKF, ODD, PROBS, OP>(p, k_lds, v_lds, qf, qbase, b, h, row0, N, fr, g, cexp);
+        if (blk + nwaves < nblocks) load_q(qbase + nwaves * 16, qn);
+        att_block<DH, NKF, ODD, PROBS, OP>(p, k_lds, v_lds, qf, qbase, b, h, row0, N, fr, g, cexp, split_wait && blk == wave);
     }
 }
 

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
     "ivit_profile_kernel_count", "ivit_profile_kernel_read", "ivit_debug_layer_tap", "ivit_debug_weight_fp8", "ivit_ln_fold_calibrate",
     "ivit_forward_host_async", "ivit_host_wait", "ivit_comm_unique_id", "ivit_comm_init", "ivit_allgather_cls",
-    "ivit_forward_device_packed", "ivit_shard_layout", "ivit_allgather_rows",
+    "ivit_forward_device_packed", "ivit_shard_layout", "ivit_allgather_rows", "ivit_layer_with_attn", "ivit_layer_with_attn_host",
 )
 
 
@@ -39,8 +39,8 @@ class IvitConfigC(ctypes.Structure):
                 ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
-ABI_VERSION = 8
-PRECISIONS = {"bf16": 0, "fp8": 1, "f16": 2, "f16x": 3}
+ABI_VERSION = 9
+PRECISIONS = {"bf16": 0, "fp8": 1, "f16": 2, "f16x": 3, "fp8m": 4}
 
 
 _lib = None
@@ -89,6 +89,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_forward_device_packed.argtypes = [c_p, c_i, c_i, c_p, c_p, c_i64, c_p]
         lib.ivit_shard_layout.argtypes = [c_i64, c_i, c_i, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]
         lib.ivit_allgather_rows.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p]
+        lib.ivit_layer_with_attn.argtypes = [c_p, c_i, c_i, c_p, c_p, c_p, c_p]
+        lib.ivit_layer_with_attn_host.argtypes = [c_p, c_i, c_i, c_p, c_p, c_i64, c_p, c_i64]
         lib.ivit_preprocess_host.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_i64, ctypes.POINTER(ctypes.c_uint64)]
         lib.ivit_preprocess.argtypes = [c_p, c_i, c_p, c_i, c_i, c_p, c_p]
         lib.ivit_forward_device.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
@@ -466,6 +468,36 @@ class Engine:
                                                     ctypes.byref(ratio), ctypes.c_void_p(stream)))
         self.ln_fold = bool(self.lib.ivit_ln_fold(self._h, 1))
         return float(ratio.value)
+
+    def layer_with_attn(self, layer: int, x: torch.Tensor):
+        """Encoder layer `layer` on a residual-stream input [N,D] / [B,N,D] with its attention map as a second result
+        (include/ivit.h: ivit_layer_with_attn): (out like the layer node, f32 [heads,N,N] / [B,heads,N,N] from the layer's own q|k|v)."""
+        batch, batched = self._split_batch(x, 3)
+        n, d, hds = self.cfg.tokens, self.cfg.dim, self.cfg.heads
+        xin = x.detach().to(torch.float32).contiguous()
+        oshape = (batch, n, d) if batched else (n, d)
+        ashape = (batch, hds, n, n) if batched else (hds, n, n)
+        if x.device.type == "cpu":
+            out = torch.empty(oshape, dtype=torch.float32)
+            attn = torch.empty(ashape, dtype=torch.float32)
+            self._check(self.lib.ivit_layer_with_attn_host(self._h, layer, batch, ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                           out.numel(), ctypes.c_void_p(attn.data_ptr()), attn.numel()))
+            return out, attn
+        if x.device.type != "cuda" or (x.device.index or 0) != self.device:
+            raise EngineError(f"input lives on {x.device}, engine on cuda:{self.device}")
+        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        attn = torch.empty(ashape, dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        self._check(self.lib.ivit_layer_with_attn(self._h, layer, batch, ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                  ctypes.c_void_p(attn.data_ptr()), ctypes.c_void_p(stream)))
+        return out, attn
+
+    def run_node_multi(self, suffix: str, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Nodes with more than one output channel: `encoder.layers.<i>.with_attn` -> {"o": layer output, "attn": attention map}."""
+        if suffix.endswith(".with_attn"):
+            out, attn = self.layer_with_attn(int(suffix.split(".")[-2]), x)
+            return {"o": out, "attn": attn}
+        return {"o": self.run_node(suffix, x)}
 
     def run_node(self, suffix: str, x: torch.Tensor) -> torch.Tensor:
         if suffix == "preprocess":

@@ -91,13 +91,20 @@ def make_vit_model_class(ModelBase, PinoutCls):
         def attn_node_names(self) -> List[str]:
             return [f"{self.prefix()}encoder.layers.{i}.attn" for i in range(self.cfg.layers)]
 
+        def with_attn_node_names(self) -> List[str]:
+            # the layer node with its attention map as a SECOND output channel ("o" continues the chain, "attn" is shipped by Response
+            # like every channel of every node, main/message.py:80-83) - SURVEY 8(f) row 4 as written.  The reference's ModelNode drops
+            # `params` (main/context.py:119-129), so the two-channel form is a node of its own rather than a parameter of the layer node.
+            return [f"{self.prefix()}encoder.layers.{i}.with_attn" for i in range(self.cfg.layers)]
+
         def list_node_names(self) -> List[str]:
             # the chain, the fused whole model, and one attention-map inspector per encoder layer
             # ([N,D] -> [heads,N,N]; put it in place of layer i at the end of a shorter chain: the
             # server graph cannot fan out)
             # ... and `preprocess`, the raw-image front end (any [3,H,W] -> what `transform` gives for [3,S,S]):
             # put it in place of `transform` when the image does not come from a client-side Resize node
-            return self.chain_node_names() + [self.prefix() + "forward", self.prefix() + "preprocess"] + self.attn_node_names()
+            return (self.chain_node_names() + [self.prefix() + "forward", self.prefix() + "preprocess"] + self.attn_node_names()
+                    + self.with_attn_node_names())
 
         def generate_graph_json(self) -> Dict:
             """Chain graph in the client's schema (graph.js:700-758), laid out exactly like
@@ -110,6 +117,14 @@ def make_vit_model_class(ModelBase, PinoutCls):
             x = pinin.get("o")
             assert x is not None
             suffix = node_name.removeprefix(self.prefix())
+            if node_name in self.with_attn_node_names():   # two output channels: "o" (the layer), "attn" ([heads,N,N])
+                with torch.no_grad():
+                    ys = self.backend.run_node_multi(suffix, x)
+                out = PinoutCls()
+                for channel in ("o", "attn"):
+                    assert isinstance(ys[channel], torch.Tensor)
+                    out.set(channel, ys[channel])
+                return out
             if suffix not in ("forward", "preprocess") and suffix not in self._suffixes and node_name not in self.attn_node_names():
                 raise KeyError(node_name)
             with torch.no_grad():
@@ -132,10 +147,13 @@ def make_vit_model_class(ModelBase, PinoutCls):
                 "heads": f"Linear &rarr; [{c.classes}]",
                 "forward": f"whole model &rarr; [{c.classes}]",
             }.get(suffix, f"attention map &rarr; [{c.heads},{c.tokens},{c.tokens}]" if suffix.endswith(".attn")
-                  else f"MHSA({c.heads} heads) + MLP({c.mlp})")
+                  else (f"MHSA({c.heads} heads) + MLP({c.mlp}); second channel attn &rarr; [{c.heads},{c.tokens},{c.tokens}]" if suffix.endswith(".with_attn")
+                        else f"MHSA({c.heads} heads) + MLP({c.mlp})"))
             return f"<p>{node_name}</p> <p>{detail}</p>"
 
         def io(self, node_name: str) -> Dict:
+            if node_name in self.with_attn_node_names():
+                return {"ins": ["o"], "outs": ["o", "attn"]}
             return {"ins": ["o"], "outs": ["o"]}
 
     return VitModel
@@ -161,7 +179,7 @@ class HipBackend:
         # (a real checkpoint's residual stream depends on its inputs); else two seeded synthetic images.  `ln_fold_threshold`: the
         # largest |mean| / std the fold is kept for (engine default 0.5); the measured ratio is kept in `ln_fold_ratio`.
         self.ln_fold_ratio = None
-        if check_ln_fold and precision != "fp8" and self.engine.ln_fold:
+        if check_ln_fold and precision not in ("fp8", "fp8m") and self.engine.ln_fold:
             if calibration_images is None:
                 # say so - uniform-noise pictures exercise the weights' own statistics, not a deployment's inputs
                 import logging
@@ -178,6 +196,9 @@ class HipBackend:
 
     def run_node(self, suffix: str, x: torch.Tensor) -> torch.Tensor:
         return self.engine.run_node(suffix, x)
+
+    def run_node_multi(self, suffix: str, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return self.engine.run_node_multi(suffix, x)
 
 
 def build_plugins(ModelBase, PinoutCls, variants: Sequence[str] = ("vit_b_16",), device: int = 0,

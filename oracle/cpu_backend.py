@@ -37,3 +37,10 @@ class OracleBackend:
     def run_node(self, suffix: str, x: torch.Tensor) -> torch.Tensor:
         y = vit_oracle.run_node_any(suffix, x.to(self.dtype), self.sd, self.cfg)
         return y.to(torch.float32)
+
+    def run_node_multi(self, suffix: str, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """`encoder.layers.<i>.with_attn`: the layer node plus its attention map as a second channel."""
+        if suffix.endswith(".with_attn"):
+            layer = suffix[:-len(".with_attn")]
+            return {"o": self.run_node(layer, x), "attn": self.run_node(layer + ".attn", x)}
+        return {"o": self.run_node(suffix, x)}

@@ -261,9 +261,16 @@ def attention(h: torch.Tensor, sd, i: int, cfg, return_probs: bool = False, emul
 
 
 def attention_map(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> torch.Tensor:
-    """Attention probabilities of layer i for a residual-stream input: [B,N,D] -> [B,H,N,N]."""
+    """Attention probabilities of layer i for a residual-stream input: [B,N,D] -> [B,H,N,N].  In the rounding-aware mode the q|k|v
+    tensor is evaluated as the ENGINE's layer call evaluates it (LN_FOLD: LayerNorm folded into the QKV GEMM) - the map the layer itself
+    attends with, which is what the `.attn` inspector and the `.with_attn` channel return since round 4."""
     dt = x.dtype
     pre = layer_prefix(i)
+    if emulate and LN_FOLD:
+        b, n, d = x.shape
+        qkv = rnd(folded_linear(x, sd[pre + "self_attention.in_proj_weight"], sd[pre + "self_attention.in_proj_bias"],
+                                sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], cfg.ln_eps, "w_qkv", _split("qkvw")), True, point="qkv")
+        return attention_core(qkv, cfg, True)[1]
     h = rnd(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), emulate, point="x")
     return attention(h, sd, i, cfg, return_probs=True, emulate=emulate)[1]
 
@@ -361,14 +368,25 @@ def q8_weight(sd, key: str, dtype) -> torch.Tensor:
     return (q * scale).to(dtype)
 
 
-def encoder_layer_fp8(x: torch.Tensor, sd, i: int, cfg, scales4) -> torch.Tensor:
+def encoder_layer_fp8(x: torch.Tensor, sd, i: int, cfg, scales4, mlp_only: bool = False) -> torch.Tensor:
     """Block i on the fp8 data path: e4m3 operands for the four GEMMs (static activation scales
-    s_h1, s_att, s_h2, s_u; per-row weight scales), bf16 q|k|v and P, f32/f64 everything else."""
+    s_h1, s_att, s_h2, s_u; per-row weight scales), bf16 q|k|v and P, f32/f64 everything else.
+    ``mlp_only`` (IVIT_PRECISION_FP8M): the attention half on the bf16 data path with LayerNorm kernels, e4m3 for MLP up / down only."""
     s_h1, s_att, s_h2, s_u = [float(v) for v in scales4]
     dt = x.dtype
     pre = layer_prefix(i)
     b, n, d = x.shape
     hd = cfg.head_dim
+    if mlp_only:
+        def r16(t):
+            return t.to(torch.float32).to(torch.bfloat16).to(dt)
+        h = r16(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps))
+        qkv = r16(h @ r16(sd[pre + "self_attention.in_proj_weight"].to(dt)).t() + _w(sd, pre + "self_attention.in_proj_bias", dt))
+        a, _ = attention_core(qkv, cfg, True, torch.bfloat16)
+        x = x + r16(a) @ r16(sd[pre + "self_attention.out_proj.weight"].to(dt)).t() + _w(sd, pre + "self_attention.out_proj.bias", dt)
+        h = q8_act(layer_norm(x, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps), s_h2)
+        u = q8_act(gelu_erf(h @ q8_weight(sd, pre + "mlp.0.weight", dt).t() + _w(sd, pre + "mlp.0.bias", dt)), s_u)
+        return x + u @ q8_weight(sd, pre + "mlp.3.weight", dt).t() + _w(sd, pre + "mlp.3.bias", dt)
     h = q8_act(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), s_h1)
     qkv = rnd(h @ q8_weight(sd, pre + "self_attention.in_proj_weight", dt).t() + _w(sd, pre + "self_attention.in_proj_bias", dt), True, torch.bfloat16)
     q, k, v = [t.reshape(b, n, cfg.heads, hd).transpose(1, 2) for t in qkv.split(d, dim=-1)]
@@ -409,7 +427,7 @@ def fp8_calibration_scales(x: torch.Tensor, sd, cfg):
     return scales
 
 
-def forward_fp8(x: torch.Tensor, sd, cfg, scales, keep: bool = False) -> Dict[str, torch.Tensor]:
+def forward_fp8(x: torch.Tensor, sd, cfg, scales, keep: bool = False, mlp_only: bool = False) -> Dict[str, torch.Tensor]:
     """Whole model on the fp8 data path: patch embedding and head as in emulate=True (bf16), every
     encoder layer through encoder_layer_fp8 with the given L*4 activation scales."""
     acts: Dict[str, torch.Tensor] = {}
@@ -418,7 +436,7 @@ def forward_fp8(x: torch.Tensor, sd, cfg, scales, keep: bool = False) -> Dict[st
     if keep:
         acts["tokens"] = t
     for i in range(cfg.layers):
-        t = encoder_layer_fp8(t, sd, i, cfg, scales[4 * i:4 * i + 4])
+        t = encoder_layer_fp8(t, sd, i, cfg, scales[4 * i:4 * i + 4], mlp_only)
         if keep:
             acts[f"encoder.layers.{i}"] = t
     t = encoder_ln(t, sd, cfg)

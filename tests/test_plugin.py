@@ -33,7 +33,8 @@ def test_registration_and_graph_file(plugin):
     cfg, sd, vit, ctx, base = plugin
     names = vit.list_node_names()
     assert names == ([f"{cfg.name}:{s}" for s in node_suffixes(cfg)] + [f"{cfg.name}:forward", f"{cfg.name}:preprocess"]
-                     + [f"{cfg.name}:encoder.layers.{i}.attn" for i in range(cfg.layers)])
+                     + [f"{cfg.name}:encoder.layers.{i}.attn" for i in range(cfg.layers)]
+                     + [f"{cfg.name}:encoder.layers.{i}.with_attn" for i in range(cfg.layers)])
     assert sorted(ctx.nodes) == sorted(names)
     assert all("/" not in n for n in names)             # node names are URL path segments (urls.py:12-13)
     gj = json.load(open(base / "static" / "graphs" / f"{cfg.name}.json"))
@@ -44,7 +45,8 @@ def test_registration_and_graph_file(plugin):
     assert len(gj["edges"]) == len(chain)               # chain edges + the edge into `category`
     assert gj["edges"][-1] == {"in_port": {"node": len(chain) - 1, "channel": "o"}, "out_port": {"node": len(chain), "channel": "o"}}
     for n in names:
-        assert ctx.get_node(n).io({}) == {"ins": ["o"], "outs": ["o"]}
+        outs = ["o", "attn"] if n.endswith(".with_attn") else ["o"]       # the two-channel layer nodes
+        assert ctx.get_node(n).io({}) == {"ins": ["o"], "outs": outs}
         assert ctx.get_node(n).contents({}).startswith(f"<p>{n}</p>")
 
 
@@ -83,6 +85,34 @@ def test_attention_map_node_shapes(plugin):
     assert amap.shape == (cfg.heads, cfg.tokens, cfg.tokens)          # [C,H,W]: what MultiView displays
     assert torch.allclose(amap.sum(-1), torch.ones(cfg.heads, cfg.tokens), atol=1e-5)
     assert ctx.get_node(chain[-1]).contents({}).startswith(f"<p>{chain[-1]}</p>")
+
+
+def test_layer_node_with_attention_channel_through_the_byte_path(plugin):
+    """SURVEY 8(f) row 4 as written: the attention map as an EXTRA OUTPUT CHANNEL of the layer node.  `encoder.layers.<i>.with_attn`
+    continues the chain through "o" and carries "attn" ([heads,N,N], a [C,H,W] tensor for MultiView, multi_view.js:53-66) beside it;
+    Response ships every channel of every node (main/message.py:80-83), so the response JSON lists both."""
+    from interactive_vit_amd.message import decode_response, encode_request
+    from interactive_vit_amd.views import compute_bytes
+    cfg, sd, vit, ctx, _ = plugin
+    img = synthetic_images(1, cfg, seed=9)[0]
+    p = cfg.name + ":"
+    chain = [p + "transform", p + "conv_proj", p + "tokens", p + "encoder.layers.0.with_attn", p + "encoder.layers.1"]
+    nodes = [{"endpoint": e, "params": {}} for e in chain]
+    edges = ([{"tensor": 0, "out_port": {"node": 0, "channel": "o"}}]
+             + [{"in_port": {"node": i, "channel": "o"}, "out_port": {"node": i + 1, "channel": "o"}} for i in range(len(chain) - 1)])
+    status, body = compute_bytes(encode_request(nodes, edges, [img]), ctx)
+    assert status == 200
+    blocks = decode_response(body)
+    assert [{"node": a, "channel": c} for a, c, _ in blocks] == [
+        {"node": 0, "channel": "o"}, {"node": 1, "channel": "o"}, {"node": 2, "channel": "o"},
+        {"node": 3, "channel": "o"}, {"node": 3, "channel": "attn"}, {"node": 4, "channel": "o"}]      # the golden response JSON: both channels of node 3
+    by = {(a, c): t for a, c, t in blocks}
+    assert by[(3, "attn")].shape == (cfg.heads, cfg.tokens, cfg.tokens) and by[(3, "o")].shape == (cfg.tokens, cfg.dim)
+    acts = vo.forward(img.unsqueeze(0), sd, cfg, keep=True)
+    assert torch.allclose(by[(3, "o")], acts["encoder.layers.0"][0], atol=1e-5)          # "o" is the plain layer node's output
+    assert torch.allclose(by[(4, "o")], acts["encoder.layers.1"][0], atol=1e-5)          # and the chain goes on through it
+    assert torch.allclose(by[(3, "attn")], vo.attention_map(acts["tokens"], sd, 0, cfg)[0], atol=1e-6)
+    assert torch.allclose(by[(3, "attn")].sum(-1), torch.ones(cfg.heads, cfg.tokens), atol=1e-5)
 
 
 def test_missing_input_and_unknown_node(plugin):

@@ -96,6 +96,50 @@ int main(int argc, char** argv) {
         }
     }
 
+    // IVIT_PAIR="a,b": two shapes of the list as a kernel PAIR - back to back on one stream against side by side on two streams (round 4:
+    // how much of a launch's epilogue / prologue phases another launch's K loops can fill; each shape on its product tile, own buffers)
+    if (const char* pr = getenv("IVIT_PAIR")) {
+        int ia = 0, ib = 0;
+        if (sscanf(pr, "%d,%d", &ia, &ib) != 2 || ia < 0 || ib < 0 || ia >= (int)shapes.size() || ib >= (int)shapes.size()) { printf("IVIT_PAIR=a,b with shape indices\n"); return 1; }
+        float *dout2, *dres2; bf16_t* dxb2; float2* dpart2;
+        CK(hipMalloc(&dout2, (size_t)maxM * maxN * 4)); CK(hipMalloc(&dres2, (size_t)maxM * maxN * 4)); CK(hipMemset(dres2, 0, (size_t)maxM * maxN * 4));
+        CK(hipMalloc(&dxb2, (size_t)maxM * maxN * 2)); CK(hipMalloc(&dpart2, (size_t)maxM * GEMM_LN_SLOTS * 8));
+        auto mk = [&](const Shape& s, float* out, float* res, bf16_t* xb, float2* part) {
+            GemmParams p{};
+            p.A = dA; p.lda = s.K; p.W = dW; p.ldw = s.K; p.M = s.M; p.N = s.N; p.K = s.K; p.bias = db; p.epi = s.epi;
+            p.out = out; p.ldo = s.N; p.resid = res; p.ldr = s.N; p.ln_part = part; p.xb = xb; p.ldxb = s.N;
+            p.ln_s = (s.epi == EPI_LNFOLD_BF16 || s.epi == EPI_LNFOLD_GELU_BF16) ? db : dzeros; p.ln_eps = 1e-6f; p.ln_dim = s.K;
+            return p;
+        };
+        const GemmParams pa = mk(shapes[ia], dout, dres, dxb, dpart), pb = mk(shapes[ib], dout2, dres2, dxb2, dpart2);
+        {   // statistics pairs for the fold epilogues
+            GemmParams r = pa; r.epi = EPI_BIAS_RESID_STATS; r.N = 768; r.K = 768; r.lda = r.ldw = 768; r.ldo = r.ldr = r.ldxb = 768; r.ln_s = nullptr;
+            CK(launch_gemm_variant(r, GEMM_TILE_160, 0)); r.out = dout2; r.resid = dres2; r.xb = dxb2; r.ln_part = dpart2; CK(launch_gemm_variant(r, GEMM_TILE_160, 0)); CK(hipDeviceSynchronize());
+        }
+        hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+        hipEvent_t ea, eb, ej; CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        const int va = gemm_pick_variant(pa.M, pa.N, pa.K), vb = gemm_pick_variant(pb.M, pb.N, pb.K);
+        std::vector<double> serial, side, alone_a, alone_b;
+        const int iters = 10;
+        for (int round = 0; round < rounds; ++round) {
+            auto timed = [&](auto body) { CK(hipDeviceSynchronize()); CK(hipEventRecord(ea, s1)); body(); CK(hipEventRecord(eb, s1)); CK(hipEventSynchronize(eb)); float ms; CK(hipEventElapsedTime(&ms, ea, eb)); return (double)ms / iters * 1e3; };
+            alone_a.push_back(timed([&] { for (int i = 0; i < iters; ++i) CK(launch_gemm_variant(pa, va, s1)); }));
+            alone_b.push_back(timed([&] { for (int i = 0; i < iters; ++i) CK(launch_gemm_variant(pb, vb, s1)); }));
+            serial.push_back(timed([&] { for (int i = 0; i < iters; ++i) { CK(launch_gemm_variant(pa, va, s1)); CK(launch_gemm_variant(pb, vb, s1)); } }));
+            side.push_back(timed([&] {
+                for (int i = 0; i < iters; ++i) {   // fork: b on s2 beside a on s1; join before the next pair
+                    CK(hipEventRecord(ej, s1)); CK(hipStreamWaitEvent(s2, ej, 0));
+                    CK(launch_gemm_variant(pa, va, s1)); CK(launch_gemm_variant(pb, vb, s2));
+                    CK(hipEventRecord(ej, s2)); CK(hipStreamWaitEvent(s1, ej, 0));
+                }
+            }));
+        }
+        auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        printf("pair %s (%s) + %s (%s): alone %.2f + %.2f = %.2f us; back to back %.2f us; side by side on two streams %.2f us\n", shapes[ia].name, gemm_variant_name(va),
+               shapes[ib].name, gemm_variant_name(vb), med(alone_a), med(alone_b), med(alone_a) + med(alone_b), med(serial), med(side));
+        return 0;
+    }
+
     int shape_idx = -1;
     for (const Shape& s : shapes) {
         ++shape_idx;
