@@ -522,7 +522,7 @@ def main():
         # returns (main/context.py:79-88), chained node to node (main/context.py:143-147): f16x meets north_star's 1e-3 over the whole
         # chain; f16 / bf16 / fp8 are bounded at their measured operand-rounding distance + 25 % (8 significant
         # bits cannot be inside 1e-3 of f32).  Against the rounding-aware oracle (the same rounding points): 1e-3 per node.
-        e2e_bound = {"f16x": 1e-3, "f16": 1.3e-3, "bf16": 1.2e-2, "fp8": 1.5e-1, "fp8m": 9e-2}[args.precision]
+        e2e_bound = {"f16x": 1e-3, "f16": 1.3e-3, "bf16": 1.2e-2, "fp8": 1.5e-1, "fp8m": 1.2e-1}[args.precision]   # fp8m: measured 8.9e-2 on ViT-H/14 (profiles/r04_bench_h14_fp8m.json) + 35 %: two correct e4m3 evaluations of 32 layers differ by 6.7e-2 from each other
         # per node vs the rounding-aware oracle: 1e-3.  ViT-H/14's layers measure 8.6e-4 on the 2 bench images (profiles/r03b_bench_h14_bf16.json)
         # and 1.02e-3 ... 1.13e-3 at B = 256 in tests/test_gpu_configs.py (five chained roundings at K = 1280 / 5120 decorrelate two correct
         # evaluations): its bound is that measurement + 15 %, not a free allowance

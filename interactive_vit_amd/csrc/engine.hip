@@ -148,9 +148,11 @@ struct Matrix {   // bf16 / f16 [rows_pad][ld], zero padded
     bf16_t* p = nullptr;
     int rows = 0, cols = 0, ld = 0;
     // split-operand forms (f16 data paths): the row is [hi | hi | lo] (split = 2: the activation operand is a
-    // [hi | lo] pair too) or [hi | lo] (split = 1: one pass over the same activations per part); each part `kpad` columns.
+    // [hi | lo] pair too; each part `kpad` columns) or hi / lo interleaved per 64-column K-tile (split = 1: both parts multiply the same
+    // activation K-tile, staged once; 2 * kpad columns).
     int split = 0, kpad = 0;
-    int a_wrap = 0;    // K-tiles of the activation operand before it repeats (GemmParams::a_wrap)
+    int a_wrap = 0;    // K-tiles of the activation operand before it repeats (GemmParams::a_wrap; split = 2)
+    int a_shift = 0;   // 1: K-tiles 2t / 2t + 1 of the product share activation K-tile t (GemmParams::a_shift; split = 1: hi / lo interleaved per K-tile)
     float* f32 = nullptr;   // split = 1 matrices that are LayerNorm-folded later (mlp.0): the f32 original, kept for ivit_weights_ready
 };
 struct Matrix8 {  // e4m3 [rows_pad][ld] (ld = round_up(cols, 128) bytes), zero padded, + per-row scales
@@ -298,7 +300,8 @@ static int alloc_matrix_split(ivit_engine* e, Matrix* m, int rows, int cols, int
     m->split = split;
     m->kpad = round_up(cols, 64);
     m->ld = (split == 2 ? 3 : 2) * m->kpad;
-    m->a_wrap = (split == 2 ? 2 : 1) * m->kpad / 64;
+    m->a_wrap = split == 2 ? 2 * m->kpad / 64 : 0;
+    m->a_shift = split == 1 ? 1 : 0;
     if (dev_alloc(e, (void**)&m->p, (size_t)round_up(rows, 256) * m->ld * sizeof(bf16_t), true)) return 1;
     return keep_f32 ? dev_alloc(e, (void**)&m->f32, (size_t)rows * cols * sizeof(float), true) : 0;
 }
@@ -618,7 +621,7 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
                     int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, const float* rowadd = nullptr,
                     int ldra = 0, int grp_in = 0, int grp_out = 0, int grp_off = 0, const LnFold* lf = nullptr, const char* role = "gemm") {
     GemmParams p{};
-    p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld; p.f16 = e->f16; p.a_wrap = W.a_wrap;
+    p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld; p.f16 = e->f16; p.a_wrap = W.a_wrap; p.a_shift = W.a_shift;
     p.bias = bias; p.epi = epi; p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr;
     p.rowadd = rowadd; p.ldra = ldra; p.grp_in = grp_in; p.grp_out = grp_out; p.grp_off = grp_off;
     if (lf) { p.ln_part = lf->part; p.ln_stats = lf->stats; p.xb = lf->xb; p.ldxb = e->D; p.ln_s = lf->s; p.ln_eps = e->cfg.ln_eps; p.ln_dim = e->D; }

@@ -47,6 +47,7 @@ struct G256Ctx {
     const bf16_t* w_src;   // same for W
     int lda, ldw;
     int a_wrap;            // GemmParams::a_wrap
+    int a_shift;           // GemmParams::a_shift
     char* smem;
     int wave;
     int a_rd[2];           // per-lane LDS read offsets inside an A half-tile for kk = 0, 1 (mf = 0)
@@ -59,7 +60,7 @@ __device__ __forceinline__ void g256_stage(const G256Ctx& c, int kt, int dst_kt,
     char* dst = c.smem + (dst_kt & 1) * Tile256P::SET_BYTES + (IS_W ? Tile256P::OFF_B0 : Tile256P::OFF_A0) + h * Tile256P::HALF_BYTES;
     if (!IS_W) {
         // piece pc = wave + 8 i  ->  half-tile rows pc*8 .. +8  ->  tile row i*128 + h*64 + wave*8 + r_in
-        int ka = kt;
+        int ka = kt >> c.a_shift;
         if (c.a_wrap) { if (ka >= c.a_wrap) ka -= c.a_wrap; if (ka >= c.a_wrap) ka -= c.a_wrap; }
         const bf16_t* s = c.a_src + (size_t)(h * 64) * c.lda + ka * GEMM_BK;
 #pragma unroll

@@ -31,6 +31,10 @@
 #pragma once
 #include "gemm256_kernel.h"
 
+#ifndef IVIT_RSG_256
+#define IVIT_RSG_256 2   // fragment rows per residual-load group of the 256 x 256 tile's f32-output epilogues (A/B builds: 1)
+#endif
+
 namespace ivit {
 
 template <int DBG, bool FP8, class OP = OpBf16>
@@ -104,7 +108,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     const int n0 = tn * T::BN;
 
     G256Ctx c;
-    c.smem = smem; c.wave = wave; c.lda = FP8 ? p.lda / 2 : p.lda; c.ldw = FP8 ? p.ldw / 2 : p.ldw; c.a_wrap = p.a_wrap;
+    c.smem = smem; c.wave = wave; c.lda = FP8 ? p.lda / 2 : p.lda; c.ldw = FP8 ? p.ldw / 2 : p.ldw; c.a_wrap = p.a_wrap; c.a_shift = p.a_shift;
     {
         const int r_in = lane >> 3;
         const int chunk = (lane & 7) ^ r_in;
@@ -148,7 +152,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
 
     if (!late) __builtin_amdgcn_s_barrier();
     IVIT_STAMP(2);
-    gemm_epilogue_family<T, EK, OP, 2>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq, tile_stats + wr * 128);
+    gemm_epilogue_family<T, EK, OP, IVIT_RSG_256>(p, acc, m0 + wr * 128, n0 + wc * 64, fr, fq, tile_stats + wr * 128);
     IVIT_STAMP(3);
     IVIT_VMCNT(0);   // the clamped tail stagings may still be writing LDS
     IVIT_STAMP(4);

@@ -21,6 +21,17 @@
 namespace ivit {
 
 constexpr int GEMM_BK = 64;
+#ifndef IVIT_RSG_2STAGE
+#define IVIT_RSG_2STAGE 1   // fragment rows per residual-load group in the two-stage kernels' _rs / _f32 epilogues.  Inside the ViT-B/16 B = 64 forward
+                            // (bench.py --steps 100, same box, alternating, medians): every row of the tile at once (T::FM) 21 531 img/s, round 3's row-by-row
+                            // form 21 619, two rows ahead 21 695, ONE row ahead 21 791 - the microbenchmark ranks them the other way round
+                            // (profiles/r04_epilogue_ab.txt): with the stream coming from the Infinity Cache, 40 MB of requests at once queue badly
+#endif
+#ifndef IVIT_ASHIFT_REUSE
+#define IVIT_ASHIFT_REUSE 1   // 0 (A/B builds): stage and read the activation K-tile for both K-tiles of a hi / lo weight pair, as round 3 did.
+                              // Only the f16 instantiations carry the branch (weight pairs exist on the f16 data path only): on the bf16 kernels it
+                              // measured -0.4 % of the headline step (profiles/r04_f16x_a_tile_reuse.txt)
+#endif
 
 template <int WAVES_M_, int WAVES_N_, int FM_, int FN_>
 struct GemmTile {
@@ -72,6 +83,7 @@ __device__ __forceinline__ f32x4 mfma_e4m3_16x16x128(const bf16x8 (&w2)[2], cons
 
 // K-tile of A that K-tile t of the product reads (GemmParams::a_wrap: at most three passes over A)
 __device__ __forceinline__ int a_ktile(const GemmParams& p, int t) {
+    t >>= p.a_shift;   // weight-only split: K-tiles 2t and 2t + 1 of the product share A's K-tile t
     if (p.a_wrap) {
         if (t >= p.a_wrap) t -= p.a_wrap;
         if (t >= p.a_wrap) t -= p.a_wrap;
@@ -828,12 +840,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
 #pragma unroll
             for (int j = 0; j < T::FN; ++j) rs_x[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if constexpr (EK == 1) {   // see RsPrefetch: the second workgroup of a CU brings its residual rows in before its K loop
+    if constexpr (EK == 1 && (IVIT_RSG_2STAGE) >= T::FM) {   // see RsPrefetch (only with the whole-tile load group): the second workgroup of a CU brings its residual rows in before its K loop
         rs_have = p.rs_prefetch_from > 0 && (int)blockIdx.x >= p.rs_prefetch_from && p.grp_in == 0 && m0 + T::BM <= p.M && n0 + T::BN <= p.N;
         if (rs_have) rs_prefetch_load<T>(p, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, rs_x);
     }
     IVIT_BODY_STAMP(1);
 
+    bf16x8 af2[T::FM][2];   // the activation fragments of the K-tile (16-bit operands): kept across a hi / lo pair of weight K-tiles (a_shift)
     // one K-tile; FOLD (first iteration of the LayerNorm-fold kernels only, a separate copy of the body so that the loop proper
     // carries neither the branch nor the prefetched registers): fold the prefetched statistics pairs right after the wait
     auto ktile = [&](int t, auto fold_tag) {
@@ -846,9 +859,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
         // the prefetched statistics pairs have landed (the wait above); fold them BEFORE the next DMA is issued (a use of an
         // ordinary load behind in-flight LDS-DMA makes hipcc wait for all of it); published by the next iteration's barrier
         if (FOLD) ln_tile_stats<T>(p, m0, tile_stats, ln_first);
+        // a_shift (weight-only split, hi / lo K-tiles alternate): K-tiles 2a and 2a + 1 multiply the same activation K-tile a - it is
+        // staged for the even one only, and its fragments stay in registers (af2) for the odd one
+        const bool a_new = !(IVIT_ASHIFT_REUSE && OP::F16 && p.a_shift && (t & 1));
         if (t + 1 < nt) {
             char* nxt = smem + ((t + 1) & 1) * T::STAGE_BYTES;
-            stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, a_ktile(p, t + 1) * 128, nxt, wave, lane);
+            if (!(IVIT_ASHIFT_REUSE && OP::F16 && p.a_shift && ((t + 1) & 1))) stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, a_ktile(p, t + 1) * 128, nxt, wave, lane);
             stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, (t + 1) * 128, nxt + T::A_BYTES, wave, lane);
         }
         const char* a_tile = cur;
@@ -874,17 +890,19 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[T::FM], wf[T::FN];
+                bf16x8 wf[T::FN];
 #pragma unroll
                 for (int j = 0; j < T::FN; ++j) wf[j] = read_frag(w_tile, (wc * T::FN + j) * 16 + fr, kk * 4 + fq);
+                if (a_new) {
 #pragma unroll
-                for (int i = 0; i < T::FM; ++i) af[i] = read_frag(a_tile, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+                    for (int i = 0; i < T::FM; ++i) af2[i][kk] = read_frag(a_tile, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+                }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < T::FM; ++i)
 #pragma unroll
                     for (int j = 0; j < T::FN; ++j)
-                        acc[i][j] = OP::mfma(wf[j], af[i], acc[i][j]);
+                        acc[i][j] = OP::mfma(wf[j], af2[i][kk], acc[i][j]);
                 __builtin_amdgcn_s_setprio(0);
             }
         }
@@ -895,7 +913,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     }
     for (int t = t_first; t < nt; ++t) ktile(t, std::false_type{});
     IVIT_BODY_STAMP(2);
-    gemm_epilogue_family<T, EK, OP>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16, rs_x, rs_have);
+    gemm_epilogue_family<T, EK, OP, IVIT_RSG_2STAGE>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16, rs_x, rs_have);
     IVIT_BODY_STAMP(3);
 #ifdef IVIT_GEMM_ABLATIONS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -935,22 +953,26 @@ __device__ __forceinline__ void gemm_body_sb(const GemmParams& p, char* smem) {
     stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, 0, smem, wave, lane);
     stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, 0, smem + T::A_BYTES, wave, lane);
     const int fr = lane & 15, fq = lane >> 4;
+    bf16x8 af[T::FM][2];   // kept across a hi / lo pair of weight K-tiles (a_shift: the odd K-tile multiplies the activation K-tile already in registers)
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        bf16x8 af[T::FM][2], wf[T::FN][2];
+        bf16x8 wf[T::FN][2];
+        const bool a_new = !(IVIT_ASHIFT_REUSE && OP::F16 && p.a_shift && (t & 1));
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int j = 0; j < T::FN; ++j) wf[j][kk] = read_frag(smem + T::A_BYTES, (wc * T::FN + j) * 16 + fr, kk * 4 + fq);
+            if (a_new) {
 #pragma unroll
-            for (int i = 0; i < T::FM; ++i) af[i][kk] = read_frag(smem, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+                for (int i = 0; i < T::FM; ++i) af[i][kk] = read_frag(smem, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();          // every wave holds its fragments: the stage may be overwritten
         if (t + 1 < nt) {
-            stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, a_ktile(p, t + 1) * 128, smem, wave, lane);
+            if (!(IVIT_ASHIFT_REUSE && OP::F16 && p.a_shift && ((t + 1) & 1))) stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, a_ktile(p, t + 1) * 128, smem, wave, lane);
             stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, (t + 1) * 128, smem + T::A_BYTES, wave, lane);
         }
         if (FP8) {   // one 128-deep scaled MFMA per fragment pair (see gemm_body)

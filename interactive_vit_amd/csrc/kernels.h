@@ -29,8 +29,10 @@ struct GemmParams {
     const bf16_t* W; int ldw;     // [N, K] bf16 row-major, rows readable up to round_up(N,256)
     int M, N, K;                  // K % 64 == 0 (operands zero-padded); fp8 operands: K % 128 == 0
     int a_wrap;                   // 0, or the number of 64-deep K-tiles A really has: K-tile t of the product reads A's K-tile t mod a_wrap.
-                                  // Split-operand GEMMs (IVIT_PRECISION_F16X): W = [W_hi | W_hi | W_lo] against A = [A_hi | A_lo] (wraps to A_hi),
-                                  // or W = [W_hi | W_lo] against a single A - hi/lo pairs of f16 values summed in the f32 accumulators
+                                  // Split-operand GEMM on pairs of BOTH operands (IVIT_PRECISION_F16X out-projection, patch, head):
+                                  // W = [W_hi | W_hi | W_lo] against A = [A_hi | A_lo] (wraps to A_hi) - hi/lo pairs of f16 values summed in the f32 accumulators
+    int a_shift;                  // 0, or 1: product K-tiles 2t and 2t + 1 read A's K-tile t - the weight-only split (MLP up / down of F16X): W's K-tiles alternate
+                                  // [hi t | lo t], so an activation K-tile is staged and its fragments are read ONCE for both passes (gemm_body / gemm_body_sb)
     int f16;                      // 0: A, W and 16-bit outputs are bf16; 1: IEEE f16 (IVIT_PRECISION_F16)
     const float* colscale;        // fp8 operands: acc *= colscale[n] (= activation scale x weight-row scale) before the bias
     float out_scale;              // EPI_BIAS_GELU_FP8: 1 / (scale of the fp8 output tensor)
@@ -151,8 +153,8 @@ hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, i
 // f32 [rows, cols] -> bf16 [rows, ldo] (columns >= cols zero)
 hipError_t launch_f32_to_bf16(const float* in, int ldi, bf16_t* out, int ldo, int rows, int cols, hipStream_t s, int f16 = 0);
 // hi/lo pairs of 16-bit values from an f32 matrix [rows, cols] (optionally times gamma[k]: the LayerNorm-folded weight from the f32
-// original, one rounding): out rows are [hi | hi | lo] (both = 1: the other operand is split too) or [hi | lo] (both = 0), each part
-// kpad columns (zero padded).  s_out / c_out (optional): s[n] = sum_k (hi + lo), c[n] = sum_k beta[k] w[n][k] + bias[n].
+// original, one rounding): out rows are [hi | hi | lo] (both = 1: the other operand is split too; each part kpad columns, zero padded)
+// or hi / lo interleaved per 64-column K-tile (both = 0: [hi t0 | lo t0 | hi t1 | ...], 2 * kpad columns; GemmParams::a_shift).  s_out / c_out (optional): s[n] = sum_k (hi + lo), c[n] = sum_k beta[k] w[n][k] + bias[n].
 hipError_t launch_split_weight(const float* w, int ldw, int rows, int cols, const float* gamma, const float* beta, const float* bias,
                                bf16_t* out, int ld_out, int kpad, int both, float* s_out, float* c_out, hipStream_t s, int f16);
 // hi/lo pair of a f32 [rows, cols] activation: out row = [hi | lo], each part ldhalf columns (zero padded)

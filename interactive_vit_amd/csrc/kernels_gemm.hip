@@ -439,9 +439,10 @@ bool gemm_persist_supported(const GemmParams&) { return false; }
 #endif
 
 // EPI_BIAS_RESID_STATS on the two-stage 160 x 128 tile, a grid of one to two workgroups per CU (out-projection / MLP down at ViT-B/16 B = 64): the
-// workgroups a CU receives second fetch their residual rows before their K loop (gemm_kernel.h: RsPrefetch).  IVIT_RS_PREFETCH=0: measurement knob.
+// workgroups a CU receives second fetch their residual rows before their K loop (gemm_kernel.h: RsPrefetch).  Study knob, OFF by default (round 4:
+// microbenchmark -3 %, whole forward 0; it needs the whole-tile load group, -DIVIT_RSG_2STAGE=5, which loses 1.2 % to the one-row-ahead default).
 static int rs_prefetch_from(const GemmParams& p, int variant) {
-    static const int mode = [] { const char* v = getenv("IVIT_RS_PREFETCH"); return v ? atoi(v) : 1; }();
+    static const int mode = [] { const char* v = getenv("IVIT_RS_PREFETCH"); return v ? atoi(v) : 0; }();
     if (!mode || variant != GEMM_TILE_160 || p.epi != EPI_BIAS_RESID_STATS || p.grp_in != 0) return 0;
     const int cus = device_cu_count(), tiles = ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN);
     return (tiles > cus && tiles <= 2 * cus) ? cus : 0;

@@ -495,9 +495,13 @@ __global__ __launch_bounds__(256) void ivit_split_weight(const float* __restrict
             s += dec16(f16, h) + dec16(f16, l);
             if (beta) c = fmaf(beta[k], wv, c);
         }
-        o[k] = h;
-        if (both) { o[kpad + k] = h; o[2 * kpad + k] = l; }
-        else o[kpad + k] = l;
+        if (both) { o[k] = h; o[kpad + k] = h; o[2 * kpad + k] = l; }
+        else {   // weight-only split: hi / lo INTERLEAVED per 64-column K-tile, [hi t0 | lo t0 | hi t1 | lo t1 | ...] - product K-tiles 2t and 2t + 1
+                 // multiply the SAME activation K-tile t (GemmParams::a_shift), which the GEMM then stages and reads once for both (round 4)
+            const int tile = k >> 6, within = k & 63;
+            o[tile * 128 + within] = h;
+            o[tile * 128 + 64 + within] = l;
+        }
     }
     s = wave_sum(s);
     c = wave_sum(c);

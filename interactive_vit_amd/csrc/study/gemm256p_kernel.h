@@ -67,7 +67,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams& p, char* smem) {
     const int n0 = tn * T::BN;
 
     G256Ctx c;
-    c.smem = smem; c.wave = wave; c.lda = p.lda; c.ldw = p.ldw; c.a_wrap = p.a_wrap;
+    c.smem = smem; c.wave = wave; c.lda = p.lda; c.ldw = p.ldw; c.a_wrap = p.a_wrap; c.a_shift = p.a_shift;
     {
         const int r_in = lane >> 3;
         const int chunk = (lane & 7) ^ r_in;   // half-tile row & 7 == r_in (pieces are 8-row aligned)
