@@ -128,7 +128,9 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float2* tile_stats = reinterpret_cast<float2*>(smem + T::LDS_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
+#if !IVIT_LN_STATS_AFTER_DMA
     if (EK == 2) ln_tile_stats<T>(p, m0, tile_stats);
+#endif
 
     const int nt = p.K / (FP8 ? 2 * GEMM_BK : GEMM_BK);
     const int last_kt = nt - 1;
@@ -140,6 +142,9 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     g256_stage<false>(c, 0, 0, 1);
     g256_stage<false>(c, k1, 1, 0);
     g256_stage<true>(c, k1, 1, 0);
+#if IVIT_LN_STATS_AFTER_DMA
+    if (EK == 2) ln_tile_stats<T>(p, m0, tile_stats);   // behind the prologue's DMA queue (the compiler's wait for these loads drains it once, here)
+#endif
     IVIT_VMCNT(8);   // A0(0), B0(0) landed; 4 half-tiles in flight
     __builtin_amdgcn_s_barrier();
     IVIT_STAMP(1);

@@ -27,6 +27,10 @@ constexpr int GEMM_BK = 64;
                             // form 21 619, two rows ahead 21 695, ONE row ahead 21 791 - the microbenchmark ranks them the other way round
                             // (profiles/r04_epilogue_ab.txt): with the stream coming from the Infinity Cache, 40 MB of requests at once queue badly
 #endif
+#ifndef IVIT_LN_STATS_AFTER_DMA
+#define IVIT_LN_STATS_AFTER_DMA 1   // _lf kernels (three-per-CU and 256 x 256 tiles): the tile's statistics pairs are loaded and folded BEHIND the first operand DMA
+                                    // (round 4, in the forward: mlp1 76.8 -> 75.9 us, qkv 55.7 -> 55.1; profiles/r04_epilogue_ab.txt (f)); 0 = in front of it, as round 3
+#endif
 #ifndef IVIT_ASHIFT_REUSE
 #define IVIT_ASHIFT_REUSE 1   // 0 (A/B builds): stage and read the activation K-tile for both K-tiles of a hi / lo weight pair, as round 3 did.
                               // Only the f16 instantiations carry the branch (weight pairs exist on the f16 data path only): on the bf16 kernels it
@@ -949,9 +953,17 @@ __device__ __forceinline__ void gemm_body_sb(const GemmParams& p, char* smem) {
     const size_t lda_b = (size_t)p.lda * ESZ, ldw_b = (size_t)p.ldw * ESZ;
     const int nt = p.K * ESZ / 128;
     float2* tile_stats = reinterpret_cast<float2*>(smem + T::STAGE_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
+#if IVIT_LN_STATS_AFTER_DMA
+    // the first K-tile's DMA is issued BEFORE the statistics pairs are loaded and folded: their latency lies under the DMA round trip the loop's
+    // first wait pays anyway (hipcc waits vmcnt(0) at the first use of the pairs - i.e. also for the DMA, which is wanted here)
+    stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, 0, smem, wave, lane);
+    stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, 0, smem + T::A_BYTES, wave, lane);
+    if (EK == 2) ln_tile_stats<T>(p, m0, tile_stats);
+#else
     if (EK == 2) ln_tile_stats<T>(p, m0, tile_stats);                          // ordinary loads: before any DMA is in flight
     stage_tile<T::A_PIECES, T::WAVES>(p.A, lda_b, m0, 0, smem, wave, lane);
     stage_tile<T::W_PIECES, T::WAVES>(p.W, ldw_b, n0, 0, smem + T::A_BYTES, wave, lane);
+#endif
     const int fr = lane & 15, fq = lane >> 4;
     bf16x8 af[T::FM][2];   // kept across a hi / lo pair of weight K-tiles (a_shift: the odd K-tile multiplies the activation K-tile already in registers)
     for (int t = 0; t < nt; ++t) {
