@@ -128,3 +128,32 @@ def test_packed_forward_writes_the_collective_block_in_place():
             eng.forward_packed(x, torch.empty((b, width - 4), dtype=torch.float32, device="cuda"), b, 0, stream)
     finally:
         eng.close()
+
+
+def test_patch_outputs_gather_through_the_same_collective():
+    """north_star: "a single RCCL all-gather ... to reassemble the [CLS]/patch outputs for the interactive view".  ivit_allgather_rows takes any
+    row width: the [b, N, D] patch outputs of encoder.ln go through it as rows of N * D floats, on a SIDE stream (issued
+    asynchronously beside the compute stream), here on a communicator of one rank - the block comes back unchanged, in image order."""
+    import torch
+    from interactive_vit_amd.engine import Engine
+    from interactive_vit_amd.vit_config import test_config as small_config
+    from interactive_vit_amd.weights import init_weights, synthetic_images
+    cfg = small_config()
+    sd = init_weights(cfg, seed=3, mode="rich")
+    eng = Engine(cfg, sd, device=0, max_batch=3)
+    try:
+        b = 3
+        x = synthetic_images(b, cfg, seed=23).cuda()
+        ln_stage = eng.stage_index("encoder.ln")
+        patches = eng.forward(x, 0, ln_stage + 1)                       # [b, N, D] f32: every token after the final LayerNorm
+        assert patches.shape == (b, cfg.tokens, cfg.dim)
+        eng.comm_init(0, 1, lambda ident: ident)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        rows = patches.reshape(b, cfg.tokens * cfg.dim).contiguous()
+        out = torch.zeros_like(rows)
+        eng.allgather_rows(rows, b, out, side.cuda_stream)
+        side.synchronize()
+        assert torch.equal(out.reshape(b, cfg.tokens, cfg.dim), patches)
+    finally:
+        eng.close()
