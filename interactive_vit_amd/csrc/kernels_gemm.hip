@@ -300,6 +300,8 @@ bool gemm_prefers_256(int M, int N, int K) {
 // shape fit one round of one workgroup per CU, every K-tile of a shallow ring is a DMA round trip - the deep-ring tile takes
 // those (tools/gemm_bench at M = 197: qkv 10.8 -> 7.3 us, proj 13.2 -> 8.1, mlp1 12.1 -> 7.9, mlp2 33.9 -> 19.3; bit-identical).
 int gemm_pick_variant(int M, int N, int K) {
+    static const int sq160 = [] { const char* v = getenv("IVIT_SQUARE_160"); return v ? atoi(v) : 0; }();   // study knob: square GEMMs (the out-projection) on three 160 x 128 per CU
+    if (sq160 && N == K && N % 4 == 0 && ceil_div(M, Tile160::BM) * ceil_div(N, Tile160::BN) > 512) return GEMM_TILE_160SB;
     if (N % 4) return GEMM_TILE_64D;   // ragged widths (a classifier of any size): the only tile whose edge epilogue guards single elements
     if (K >= 2 * GEMM_BK && ceil_div(M, Tile64D::BM) * ceil_div(N, Tile64D::BN) <= 256) return GEMM_TILE_64D;
     if (gemm_prefers_256(M, N, K)) return GEMM_TILE_256S;
@@ -497,6 +499,9 @@ hipError_t launch_gemm_variant(const GemmParams& p_in, int variant, hipStream_t 
 
 // fp8 operands: the three-per-CU tiles or the 256 x 256 staggered tile, under the 16-bit rule (no deep-ring form: small fp8 grids take 160 x 128)
 static int fp8_tile(const GemmParams& p) {
+    // the square out-projection (N = K = D, f32 residual epilogue) on three 160 x 128 workgroups per CU: 226.7 against 232.3 us at ViT-H/14 B = 256
+    // (its read-modify-write burst is exposed at one workgroup per CU; round 4, in the forward: 3 865 -> 3 888 img/s)
+    if (p.N == p.K && p.epi == EPI_BIAS_RESID_F32 && ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) >= 256) return GEMM_TILE_160SB;
     if (gemm_prefers_256(p.M, p.N, p.K)) return GEMM_TILE_256S;
     return ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) >= 256 ? GEMM_TILE_160SB : GEMM_TILE_128SB;
 }

@@ -277,8 +277,8 @@ def test_config5_vit_h14_batch256_bf16_as_dispatched():
 
 def test_config5_vit_h14_batch256_fp8_as_dispatched():
     """BASELINE configs[4]: e4m3 weights + activations on the 2x-rate scaled MFMA, 256x256x128 tile."""
-    k = "ivit_gemm_fp8_256x256x128_stag"
-    run_config("vit_h_14", 256, "fp8", {"qkv": k, "proj": k + "_f32", "mlp1": k, "mlp2": k + "_f32"},
+    k = "ivit_gemm_fp8_256x256x128_stag"     # (the square out-projection: three 160 x 128 workgroups per CU, round 4)
+    run_config("vit_h_14", 256, "fp8", {"qkv": k, "proj": "ivit_gemm_fp8_160x128x128_sb_f32", "mlp1": k, "mlp2": k + "_f32"},
                expect_fold=False, layers_to_check=(0, 31), layer_tol=3e-2)     # whole layer: five chained quantisations on a 2^-4 grid; the per-step gates above are the strict ones
 
 
