@@ -24,6 +24,10 @@
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef IVIT_ATT_WIDE_STORES
+#define IVIT_ATT_WIDE_STORES 1
+#endif
+
 namespace ivit {
 
 // Head dims: 64 (ViT-Ti/B/L: 128-B LDS rows, XOR-swizzled chunks) and 80 (ViT-H/14: 160 B of data in
@@ -193,12 +197,31 @@ __device__ __forceinline__ void att_block(const AttnParams& p, const char* k_lds
     // (the guard diverges only here, after the last transposed read of this block, which needs
     // EXEC all ones; the next block's reads run with the full mask again)
     const int q = qbase + fr;
-    if (q < N && p.out8) {   // fp8 data path: 4 consecutive d -> one dword of e4m3
-        unsigned char* orow8 = p.out8 + (row0 + q) * p.ldo8 + h * ATT_DH + g * 4;
-        const float sc = inv * p.scale8;
+    if (p.out8) {   // fp8 data path: 4 consecutive d -> one dword of e4m3
+        if (q < N) {
+            unsigned char* orow8 = p.out8 + (row0 + q) * p.ldo8 + h * ATT_DH + g * 4;
+            const float sc = inv * p.scale8;
 #pragma unroll
-        for (int d = 0; d < L::NDB; ++d)
-            *reinterpret_cast<unsigned int*>(orow8 + d * 16) = pack_fp8x4(o[d][0] * sc, o[d][1] * sc, o[d][2] * sc, o[d][3] * sc);
+            for (int d = 0; d < L::NDB; ++d)
+                *reinterpret_cast<unsigned int*>(orow8 + d * 16) = pack_fp8x4(o[d][0] * sc, o[d][1] * sc, o[d][2] * sc, o[d][3] * sc);
+        }
+    } else if (IVIT_ATT_WIDE_STORES && NKF < 38 && !p.lo_off) {   // (the 577-key instantiation has no registers left for the swap: 12 bytes of scratch)
+        // 16-byte stores (round 4): lane groups g / g ^ 1 trade the quads of a column-block PAIR (d, d + 1) through v_permlane16_swap, as the GEMM
+        // epilogues do - even groups end up with 8 consecutive columns of block d, odd groups of block d + 1.  The swap needs every lane (EXEC all
+        // ones), so it runs in front of the q < N guard; rows past N compute on clamped garbage and store nothing.
+        bf16_t* orow = p.out + (row0 + q) * p.ldo + h * ATT_DH;
+#pragma unroll
+        for (int d = 0; d + 1 < L::NDB; d += 2) {
+            const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(o[d][0] * inv, o[d][1] * inv), OP::pack2(o[d + 1][0] * inv, o[d + 1][1] * inv), false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(o[d][2] * inv, o[d][3] * inv), OP::pack2(o[d + 1][2] * inv, o[d + 1][3] * inv), false, false);
+            u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
+            if (q < N) *reinterpret_cast<u32x4*>(orow + (d + (g & 1)) * 16 + (g & ~1) * 4) = pk;
+        }
+        if (L::NDB & 1) {   // head dim 80: the fifth column block keeps its 8-byte stores
+            constexpr int d = L::NDB - 1;
+            u32x2 pk2 = {OP::pack2(o[d][0] * inv, o[d][1] * inv), OP::pack2(o[d][2] * inv, o[d][3] * inv)};
+            if (q < N) *reinterpret_cast<u32x2*>(orow + d * 16 + g * 4) = pk2;
+        }
     } else if (q < N) {
         bf16_t* orow = p.out + (row0 + q) * p.ldo + h * ATT_DH + g * 4;
 #pragma unroll
