@@ -9,6 +9,7 @@ typedef uint16_t bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // one 16x16 MFMA accumulator fragment
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // one 32x32 MFMA accumulator fragment
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -53,7 +54,13 @@ __device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
 struct OpBf16 {
     static constexpr bool F16 = false;
     static __device__ __forceinline__ f32x4 mfma(const bf16x8& w, const bf16x8& a, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(const bf16x8& w, const bf16x8& a, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0); }
     static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    // acc + the two 16-bit values of a packed pair (v_dot2c_f32_bf16 against 1.0 | 1.0)
+    static __device__ __forceinline__ float add_pair(unsigned int pk, float acc) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pk), __builtin_bit_cast(bf2, 0x3f803f80u), acc, false);
+    }
     static __device__ __forceinline__ bf16_t from_f32(float x) { return f2bf(x); }
     static __device__ __forceinline__ float to_f32(bf16_t b) { return bf2f(b); }
 };
@@ -63,7 +70,14 @@ struct OpF16 {
     static __device__ __forceinline__ f32x4 mfma(const bf16x8& w, const bf16x8& a, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, w), __builtin_bit_cast(h8, a), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x16 mfma32(const bf16x8& w, const bf16x8& a, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, w), __builtin_bit_cast(h8, a), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+    static __device__ __forceinline__ float add_pair(unsigned int pk, float acc) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, pk), __builtin_bit_cast(h2, 0x3c003c00u), acc, false);
+    }
     static __device__ __forceinline__ bf16_t from_f32(float x) { return __builtin_bit_cast(bf16_t, (_Float16)x); }
     static __device__ __forceinline__ float to_f32(bf16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
 };

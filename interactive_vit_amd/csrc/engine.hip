@@ -672,7 +672,7 @@ static int run_attention(ivit_engine* e, const Ws& w, hipStream_t st, int B, uns
     ap.probs = nullptr;
     ap.out8 = out8; ap.ldo8 = e->ld8d; ap.scale8 = scale8;
     const double flops = 4.0 * B * e->cfg.heads * (double)e->N * e->N * e->dh;
-    ProfScope ps(e, PC_ATTN, st, flops, 2.0 * M * 3.0 * D + (out8 ? 1.0 : 2.0) * M * D);
+    ProfScope ps(e, PC_ATTN, st, flops, 2.0 * M * 3.0 * D + (out8 ? 1.0 : 2.0) * M * D, nullptr, attention_kernel_name(ap));
     HIP_TRY(launch_attention(ap, st));
     return 0;
 }

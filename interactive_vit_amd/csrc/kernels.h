@@ -95,6 +95,7 @@ struct AttnParams {
     float scale8;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+const char* attention_kernel_name(const AttnParams& p);   // "ivit_attention_bf16" (one pass, <= 288 tokens or head dim 80) or "ivit_attention_q32"
 bool attention_supported(int tokens, int head_dim);
 
 #ifdef IVIT_GEMM_ABLATIONS   // study kernel (csrc/study/fused_qkv_attention.inc), microbenchmark builds only

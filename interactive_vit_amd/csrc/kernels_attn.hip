@@ -381,6 +381,331 @@ __global__ __launch_bounds__(1024) void ivit_attention_pipe(AttnParams p, int it
 
 #endif
 
+
+// ---------------------------------------------------------------- long sequences (round 4): 32 queries per wave, key tiles of 32, 32x32x16 MFMA
+// At 577 keys the one-pass kernel above keeps 152 score registers per lane live (256 VGPRs, two waves per SIMD): LDS reads, softmax VALU and
+// MFMA of a wave run back to back, 44 us per workgroup.  ivit_attention_q32 keeps the whole head resident in LDS too (K and V staged once by
+// LDS-DMA), but a wave owns a block of 32 queries and walks the keys in tiles of 32 with v_mfma_f32_32x32x16 (half the LDS bytes and half
+// the MFMA issue slots per FLOP of the 16x16x32 form), one score tile live at a time:
+//   S^T tile = K_t . Q^T   A = K rows (ds_read_b128: lane (key = l & 31, hi = l >> 5) reads d = 16 kk + 8 hi .. +7), B = Q fragments in registers
+//              -> lane (q = l & 31, hi) holds S[q][key = 32 t + (r & 3) + 8 (r >> 2) + 4 hi], r = 0..15
+//   O^T += V_t^T . P^T     B = P straight from those registers (k-slot 8 hi + j of step s = register 8 s + j), A = V^T by ds_read_b64_tr_b16
+//              -> lane holds O[q][d = 32 dblk + (r & 3) + 8 (r >> 2) + 4 hi]
+// What was measured on the way (tools/attn_bench, tools/simd_share_probe; profiles/r04_attention_long.txt): a software-pipelined form with
+// two waves per SIMD (QK^T of tile t + 1 issued under the softmax of tile t, hand-placed MFMA / VALU interleave) ran at the same 300 - 320 us
+// per ViT-L launch as this one: the SIMD's issue port is the bound (v_exp_f32, v_cvt_pk_bf16_f32, v_dot2c and v_max3 cost 8 - 10 cycles each
+// whoever issues them, every other instruction ~ 2.5 - 5), so the instruction count per key tile decides, not the order.
+struct AttLayout32 {   // head dim 64: 128-B rows of 8 chunks; K chunk slot = ch ^ ((key >> 1) & 7) (ds_read_b128 by 32 keys x one chunk: conflict free),
+    static constexpr int ROW = 128, TILE = 32 * ROW;   // V chunk slot = ch ^ (((key >> 1) & 1) << 2) (tr reads of 4 keys x 32 d per half wave: conflict free)
+    static constexpr int K_SWZ = 0, V_SWZ = 1;
+    __device__ static int swz(int which, int key) { return which == K_SWZ ? ((key >> 1) & 7) : (((key >> 1) & 1) << 2); }
+};
+
+__device__ __forceinline__ void att_stage32(char* lds, const bf16_t* src0, int ld, int N, int rows, int which, int wave, int nwaves, int lane) {
+    const int instr = rows >> 3;   // one DMA instruction = 64 chunk slots = 8 rows
+    for (int i = wave; i < instr; i += nwaves) {
+        const int slot = i * 64 + lane;
+        const int key = slot >> 3, cl = slot & 7;
+        if (key < N) {
+            const int ch = cl ^ AttLayout32::swz(which, key);
+            __builtin_amdgcn_global_load_lds((const IVIT_GLOBAL void*)(src0 + (size_t)key * ld + ch * 8), (IVIT_LDS void*)(lds + i * 1024), 16, 0, 0);
+        } else {
+            *reinterpret_cast<u32x4*>(lds + slot * 16) = u32x4{0u, 0u, 0u, 0u};   // 0 * garbage must not be NaN in P.V
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x4 lds_read_tr16(IVIT_LDS const char* lds_addr) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((IVIT_LDS s16x4*)lds_addr);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+// both lanes of a pair (l, l ^ 32) get the value of the low lane in `lo` and of the high lane in `hi`
+__device__ __forceinline__ void pair_exchange(float x, float& lo, float& hi) {
+    // (hipcc 7.2 folds max / add of the two results of one swap of the SAME value into an operation on result 0 alone; the empty asm on the
+    // results keeps them apart)
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned int, x), __builtin_bit_cast(unsigned int, x), false, false);
+    unsigned int a = r[0], b = r[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+    lo = __builtin_bit_cast(float, a);
+    hi = __builtin_bit_cast(float, b);
+}
+
+// No software pipeline across key tiles: a wave needs < 128 registers and a workgroup runs up to 16 waves, four per SIMD (one wave alone
+// issues a vector instruction every >= 5 cycles).
+//  * Reference exponent: m = ceil(c x the row's maximum over the FIRST key tile a wave sees); numerators 2^(c s - m) of later tiles may
+//    exceed 1 (a 16-bit float keeps its relative precision at any scale; sums are f32), so the tile loop has no maximum, no branch and no
+//    rescale.  A numerator that left the 16-bit range shows up as a non-finite row sum; that block is then redone with the true maximum of
+//    the rows concerned (never seen on real activations; the other rows repeat their first evaluation bit for bit).
+//  * Balance: nt query blocks on W waves leave L = nt mod W blocks over (577 tokens: 19 blocks, 16 waves, 3 over).  One wave each for them
+//    would run alone on its SIMD for a whole block time, at the rate of a lone wave.  Instead every leftover block is shared by W / L waves,
+//    each taking a slice of the key tiles with its own reference exponent; the partial (O, sum, m) go through LDS - the K / V images are
+//    dead by then - and the first wave of the group adds them up scaled by exact powers of two.
+template <class OP, int MAXW>
+__global__ __launch_bounds__(MAXW * 64) void ivit_attention_q32(AttnParams p, int nt) {
+    using L = AttLayout32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rows = nt * 32;
+    char* k_lds = smem;
+    char* v_lds = smem + rows * L::ROW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int N = p.tokens;
+    const int D = p.heads * 64;
+    const size_t row0 = (size_t)b * N;
+    const bf16_t* qkv = p.qkv;
+    const int ld = p.ldqkv;
+
+    att_stage32(k_lds, qkv + row0 * ld + h * 64 + D, ld, N, rows, L::K_SWZ, wave, nwaves, lane);
+    att_stage32(v_lds, qkv + row0 * ld + h * 64 + 2 * D, ld, N, rows, L::V_SWZ, wave, nwaves, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float cexp = p.scale * 1.44269504088896340736f;
+
+    // per-lane LDS addresses as address-space-3 pointers (tile offsets become instruction immediates), recomputed per slice (registers) and
+    // opaque to the compiler, which otherwise keeps them relative to the dynamic-LDS base and re-adds that base - a literal 0 - at every read
+    typedef IVIT_LDS const char* lds_ptr;
+    lds_ptr kp[4], vp[2];
+    auto set_tile = [&](int t) {
+        lds_ptr lds0 = (lds_ptr)smem + t * L::TILE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kp[kk] = lds0 + ql * L::ROW + (((2 * kk + hi) ^ ((ql >> 1) & 7)) << 4);
+        const int gg = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;   // transposed read: lane 4 q4 + pp of a 16-lane group supplies &V[key0 + q4][d0 + 4 pp]
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk) {
+            const int c = 4 * dblk + 2 * (gg & 1) + (pp >> 1);
+            vp[dblk] = lds0 + rows * L::ROW + (4 * hi + q4) * L::ROW + ((c ^ ((q4 >> 1) << 2)) << 4) + (pp & 1) * 8;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(kp[kk]));
+        asm volatile("" : "+v"(vp[0]), "+v"(vp[1]));
+    };
+
+    bf16x8 qf[4];
+    auto load_q = [&](int qbase) {   // B operand of S^T: lane holds Q[qbase + ql][16 kk + 8 hi .. +7]; rows past N repeat the last one (never stored)
+        const int qrow = min(qbase + ql, N - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * 64 + kk * 16 + hi * 8);
+    };
+    // S^T of the key tile at kp + off.  No masking: K rows past N are zeros in LDS, so such a key scores exactly 0, its numerator is the
+    // same 2^-m for every one of them, and V's rows past N are zeros too - O is right as it is and the row sum is put right once per block.
+    auto qk = [&](f32x16& a, int off) {
+        bf16x8 kf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<IVIT_LDS const bf16x8*>(kp[kk] + off);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a = OP::mfma32(kf[kk], qf[kk], a);
+    };
+    auto row_max = [&](const f32x16& a) {   // over the 32 keys of a tile: this lane's 16 and its partner's
+        float ta = fmaxf(fmaxf(a[0], a[1]), a[2]), tb = fmaxf(fmaxf(a[3], a[4]), a[5]);
+#pragma unroll
+        for (int r = 6; r < 14; r += 4) { ta = fmaxf(fmaxf(ta, a[r]), a[r + 1]); tb = fmaxf(fmaxf(tb, a[r + 2]), a[r + 3]); }
+        float xa, xb;
+        pair_exchange(fmaxf(fmaxf(ta, tb), fmaxf(a[14], a[15])), xa, xb);
+        return fmaxf(xa, xb);
+    };
+    int npad = 0;   // how many of this lane's 16 keys of the LAST tile lie past N
+    {
+        const int lim = N - 32 * (nt - 1) - 4 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) npad += ((r & 3) + 8 * (r >> 2) >= lim) ? 1 : 0;
+    }
+    f32x16 o0, o1;
+    float m_row, sum;   // sum: this lane's half of the row sum
+    // key tiles [t0, t1) of the query block in qf -> o0, o1, sum, m_row
+    auto tiles = [&](int t0, int t1) {
+        f32x16 s;
+        auto body = [&](int off) {   // the tile at vp + off (its scores are in s), then the scores of the tile after it
+            union { bf16x8 v; bf16x4 h2[2]; } vf[2][2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int dblk = 0; dblk < 2; ++dblk) {
+                    vf[st][dblk].h2[0] = lds_read_tr16(vp[dblk] + off + (16 * st) * L::ROW);
+                    vf[st][dblk].h2[1] = lds_read_tr16(vp[dblk] + off + (16 * st + 8) * L::ROW);
+                }
+            const float nm = -m_row;
+            union { bf16x8 v; unsigned int u[4]; } pk[2];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(s[r], cexp, nm));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], cexp, nm));
+                const unsigned int pr = OP::pack2(e0, e1);
+                sum = OP::add_pair(pr, sum);   // the row sum is the sum of the ROUNDED numerators: O / sum is a convex combination of V rows
+                pk[r >> 3].u[(r & 7) >> 1] = pr;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                o0 = OP::mfma32(vf[st][0].v, pk[st].v, o0);
+                o1 = OP::mfma32(vf[st][1].v, pk[st].v, o1);
+            }
+            qk(s, off + L::TILE);   // (behind the last tile of the slice: one tile further in LDS - at worst the head of V's image - and never used)
+        };
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+            sum = 0.f;
+            set_tile(t0);
+            qk(s, 0);
+            if (pass == 0) m_row = ceilf(row_max(s) * cexp);
+            int rem = t1 - t0;
+            if (MAXW <= 12) {   // (two tiles a turn where the register budget allows: 3 waves per SIMD, 170 registers)
+#pragma unroll 1
+                for (; rem >= 2; rem -= 2) {
+                    body(0);
+                    body(L::TILE);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) kp[kk] += 2 * L::TILE;
+                    vp[0] += 2 * L::TILE; vp[1] += 2 * L::TILE;
+                }
+            }
+#pragma unroll 1
+            for (; rem >= 1; --rem) {
+                body(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) kp[kk] += L::TILE;
+                vp[0] += L::TILE; vp[1] += L::TILE;
+            }
+            if (t1 == nt) sum -= (float)npad * OP::to_f32(OP::from_f32(__builtin_amdgcn_exp2f(-m_row)));   // the keys past N: score 0, numerator rn16(2^-m) each
+            if (pass == 1) break;
+            float sa, sb;
+            pair_exchange(sum, sa, sb);
+            const bool bad = !(fabsf(sa + sb) < INFINITY);   // a numerator left the 16-bit range (or the input was not finite)
+            if (__builtin_amdgcn_ballot_w64(bad) == 0) break;
+            float mx = -INFINITY;   // the true maximum of the slice, for the rows that need it (padded keys count as 0: harmless, m is only a reference)
+            set_tile(t0);
+#pragma unroll 1
+            for (int t = t0; t < t1; ++t) {
+                qk(s, 0);
+                mx = fmaxf(mx, row_max(s));
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) kp[kk] += L::TILE;
+            }
+            if (bad) m_row = ceilf(mx * cexp);
+        }
+    };
+    // O = (o0 | o1) * inv of the query block at qbase -> memory
+    auto store_block = [&](int qbase, float inv) {
+        const int q = qbase + ql;
+        if (p.out8) {
+            if (q < N) {
+                unsigned char* orow8 = p.out8 + (row0 + q) * p.ldo8 + h * 64 + hi * 4;
+                const float sc8 = inv * p.scale8;
+#pragma unroll
+                for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x16& o = dblk ? o1 : o0;
+                        *reinterpret_cast<unsigned int*>(orow8 + dblk * 32 + j * 8) = pack_fp8x4(o[4 * j] * sc8, o[4 * j + 1] * sc8, o[4 * j + 2] * sc8, o[4 * j + 3] * sc8);
+                    }
+            }
+        } else if (p.lo_off) {   // high and low parts for the split-operand out-projection
+            if (q < N) {
+                bf16_t* orow = p.out + (row0 + q) * p.ldo + h * 64 + hi * 4;
+#pragma unroll
+                for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x16& o = dblk ? o1 : o0;
+                        float v[4], lo[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] = o[4 * j + r] * inv; lo[r] = v[r] - OP::to_f32(OP::from_f32(v[r])); }
+                        *reinterpret_cast<u32x2*>(orow + dblk * 32 + j * 8) = u32x2{OP::pack2(v[0], v[1]), OP::pack2(v[2], v[3])};
+                        *reinterpret_cast<u32x2*>(orow + p.lo_off + dblk * 32 + j * 8) = u32x2{OP::pack2(lo[0], lo[1]), OP::pack2(lo[2], lo[3])};
+                    }
+            }
+        } else {
+            // 16-byte stores: the lanes of a pair hold d = 8 j + 0..3 (hi = 0) and 8 j + 4..7 (hi = 1); v_permlane32_swap on the groups j, j + 1
+            // leaves the low lane with all 8 columns of group j and the high lane with those of group j + 1.  (EXEC all ones: in front of the guard)
+            bf16_t* orow = p.out + (row0 + q) * p.ldo + h * 64 + hi * 8;
+#pragma unroll
+            for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x16& o = dblk ? o1 : o0;
+                    const auto ra = __builtin_amdgcn_permlane32_swap(OP::pack2(o[4 * j] * inv, o[4 * j + 1] * inv), OP::pack2(o[4 * j + 4] * inv, o[4 * j + 5] * inv), false, false);
+                    const auto rb = __builtin_amdgcn_permlane32_swap(OP::pack2(o[4 * j + 2] * inv, o[4 * j + 3] * inv), OP::pack2(o[4 * j + 6] * inv, o[4 * j + 7] * inv), false, false);
+                    const u32x4 pkk = {ra[0], rb[0], ra[1], rb[1]};
+                    if (q < N) *reinterpret_cast<u32x4*>(orow + dblk * 32 + j * 8) = pkk;
+                }
+        }
+    };
+
+    // ---- whole blocks: wave w takes blocks w, w + W, ... below full * W
+    const int full = nt / nwaves, left = nt - full * nwaves;
+#pragma unroll 1
+    for (int k = 0; k < full; ++k) {
+        const int qbase = (wave + k * nwaves) * 32;
+        load_q(qbase);
+        tiles(0, nt);
+        float sa, sb;
+        pair_exchange(sum, sa, sb);
+        store_block(qbase, 1.0f / (sa + sb));
+    }
+    if (left == 0) return;   // (wave-uniform for the whole workgroup: nobody waits at the barriers below)
+
+    // ---- leftover blocks: block full * W + j is shared by the waves [ceil(j W / L), ceil((j + 1) W / L)), a slice of the key tiles each
+    const int j = wave * left / nwaves;
+    const int w0 = (j * nwaves + left - 1) / left, w1 = ((j + 1) * nwaves + left - 1) / left;
+    const int g = w1 - w0, pos = wave - w0;
+    const int t0 = pos * nt / g, t1 = (pos + 1) * nt / g;   // (g <= W <= nt: no slice is empty)
+    const int qbase = (full * nwaves + j) * 32;
+    load_q(qbase);
+    tiles(t0, t1);
+    __builtin_amdgcn_s_barrier();   // every wave is done with the K / V images
+    // partial of wave w: 34 rows of 64 floats at w * PART (lane-wise: the combining wave reads its own register layout back)
+    constexpr int PART = 34 * 256;
+    float* mine = reinterpret_cast<float*>(smem + wave * PART) + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mine[r * 64] = o0[r]; mine[(16 + r) * 64] = o1[r]; }
+    mine[32 * 64] = sum;
+    mine[33 * 64] = m_row;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (pos != 0) return;
+    float mtop = m_row;
+#pragma unroll 1
+    for (int i = 1; i < g; ++i) mtop = fmaxf(mtop, (reinterpret_cast<const float*>(smem + (w0 + i) * PART) + lane)[33 * 64]);
+    {
+        const float f = __builtin_amdgcn_exp2f(m_row - mtop);   // integers: an exact power of two
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= f; o1[r] *= f; }
+        sum *= f;
+    }
+#pragma unroll 1
+    for (int i = 1; i < g; ++i) {
+        const float* other = reinterpret_cast<const float*>(smem + (w0 + i) * PART) + lane;
+        const float f = __builtin_amdgcn_exp2f(other[33 * 64] - mtop);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = fmaf(other[r * 64], f, o0[r]); o1[r] = fmaf(other[(16 + r) * 64], f, o1[r]); }
+        sum = fmaf(other[32 * 64], f, sum);
+    }
+    float sa, sb;
+    pair_exchange(sum, sa, sb);
+    store_block(qbase, 1.0f / (sa + sb));
+}
+
+template <class OP, int MAXW>
+static hipError_t launch_q32_op(const AttnParams& p, hipStream_t stream) {
+    const int nt = ceil_div(p.tokens, 32);
+    const int lds = 2 * nt * AttLayout32::TILE;
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ivit_attention_q32<OP, MAXW>), 2 * 19 * AttLayout32::TILE);
+    if (e != hipSuccess) return e;
+    int waves = std::min(MAXW, nt);
+#ifdef IVIT_GEMM_ABLATIONS
+    { static const int w = [] { const char* v = getenv("IVIT_ATT_WAVES"); return v ? atoi(v) : 0; }(); if (w > 0) waves = std::min(std::min(w, MAXW), nt); }   // study knob
+#endif
+    hipLaunchKernelGGL((ivit_attention_q32<OP, MAXW>), dim3(1, p.heads, p.batch), dim3(waves * 64), lds, stream, p, nt);
+    return hipGetLastError();
+}
+
 bool attention_supported(int tokens, int head_dim) {
     if (tokens < 1) return false;
     if (head_dim == 64) return tokens <= 38 * 16;
@@ -434,10 +759,31 @@ static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
     return p.probs ? launch_nkf_impl<DH, NKF, false, true>(p, stream) : launch_nkf_impl<DH, NKF, false, false>(p, stream);
 }
 
+#ifdef IVIT_GEMM_ABLATIONS
+static int att32_force() { static const int force = [] { const char* v = getenv("IVIT_ATT32"); return v ? atoi(v) : -1; }(); return force; }   // study knob: 0 never, 1 whenever head dim 64, 2 the same with 12 waves
+#endif
+// Which kernel: the 32-query tiled form from 289 tokens on at head dim 64 (measured at B x H = 2048 heads, tools/attn_bench: 257 tokens 88.6 us
+// against 90.5 for the one-pass form, 325 tokens 141 against 180, 417 tokens 212 against 268, 577 tokens 332 against 376; 197 tokens 51.6 against
+// 47.0).  The inspection variant (probabilities written out) stays on the one-pass form.
+static bool use_q32(const AttnParams& p) {
+    bool q32 = p.head_dim == 64 && !p.probs && p.tokens > 288;
+#ifdef IVIT_GEMM_ABLATIONS
+    if (att32_force() >= 0) q32 = att32_force() && p.head_dim == 64 && !p.probs;
+#endif
+    return q32;
+}
+const char* attention_kernel_name(const AttnParams& p) { return use_q32(p) ? "ivit_attention_q32" : "ivit_attention_bf16"; }
+
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (!attention_supported(p.tokens, p.head_dim)) return hipErrorInvalidValue;
     if ((p.ldqkv % 8) || (!p.probs && !p.out8 && (p.ldo % 4)) || (p.out8 && (p.ldo8 % 4))) return hipErrorInvalidValue;
     const int nkf = round_up(ceil_div(p.tokens, 16), 2);
+    if (use_q32(p)) {
+#ifdef IVIT_GEMM_ABLATIONS
+        if (att32_force() == 2) return p.f16 ? launch_q32_op<OpF16, 12>(p, stream) : launch_q32_op<OpBf16, 12>(p, stream);
+#endif
+        return p.f16 ? launch_q32_op<OpF16, 16>(p, stream) : launch_q32_op<OpBf16, 16>(p, stream);
+    }
     if (p.head_dim == 80) {
         if (nkf <= 2) return launch_nkf<80, 2>(p, stream);
         if (nkf <= 8) return launch_nkf<80, 8>(p, stream);

@@ -223,10 +223,31 @@ def gelu_erf(x: torch.Tensor) -> torch.Tensor:
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
+def engine_attention_form(tokens: int, head_dim: int) -> str:
+    """Which attention kernel the engine launches for P.V (kernels_attn.hip: use_q32): "q32" from 289 tokens on at head dim 64, else "one-pass"
+    (the attention-map inspector is always the one-pass form).  tests/test_gpu_configs.py asserts the kernel names per configuration."""
+    return "q32" if head_dim == 64 and tokens > 288 else "one-pass"
+
+
+def _pv_emulated(sc: torch.Tensor, v: torch.Tensor, p_dtype=None, point="p"):
+    """softmax(sc) v as the engine's attention kernel evaluates it, scores sc [B,H,N,N] already scaled, v [B,H,N,dh] -> [B,H,N,dh]."""
+    if engine_attention_form(sc.shape[-1], v.shape[-1]) == "q32":
+        # ivit_attention_q32: numerators 2^(c s - m) with an INTEGER reference exponent m (the kernel takes ceil(c max) over the first key tile
+        # a wave sees; any integer gives the same rounded numerators up to an exact power of two), rounded to 16 bits; the row sum is the sum
+        # of the ROUNDED numerators
+        l2 = sc * math.log2(math.e)
+        pr = rnd(torch.exp2(l2 - torch.ceil(l2.amax(dim=-1, keepdim=True))), True, p_dtype, point=point)
+        return (pr @ v) / pr.sum(dim=-1, keepdim=True)
+    # one-pass kernel: numerators exp(s - max), rounded to 16 bits for P.V; the row sum is the sum of the UNROUNDED numerators
+    e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+    return (rnd(e, True, p_dtype, point=point) @ v) / e.sum(dim=-1, keepdim=True)
+
+
 def attention_core(qkv: torch.Tensor, cfg, emulate: bool = False, p_dtype=None):
     """Scaled-dot-product attention on a stored q|k|v tensor [B,N,3D] -> (output [B,N,D] before any rounding,
-    probabilities [B,H,N,N]).  emulate: the engine's evaluation - numerators e = exp(s - max) in f32/f64, row sum
-    of the UNROUNDED e, P.V on the 16-bit copy of e (``p_dtype`` pins that type where the engine's policy does)."""
+    probabilities [B,H,N,N]).  emulate: the engine's evaluation - one-pass kernel: numerators e = exp(s - max) in f32/f64, row sum
+    of the UNROUNDED e, P.V on the 16-bit copy of e (``p_dtype`` pins that type where the engine's policy does); 32-query tiled kernel
+    (engine_attention_form): see below."""
     b, n, d3 = qkv.shape
     d = d3 // 3
     hd = cfg.head_dim
@@ -238,9 +259,8 @@ def attention_core(qkv: torch.Tensor, cfg, emulate: bool = False, p_dtype=None):
     q, k, v = heads(q), heads(k), heads(v)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
     if emulate:
-        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
-        p = e / e.sum(dim=-1, keepdim=True)
-        a = (rnd(e, True, p_dtype, point="p") @ v) / e.sum(dim=-1, keepdim=True)
+        p = torch.softmax(s, dim=-1)   # (the probabilities the attention-map inspector writes: unrounded numerators over their sum)
+        a = _pv_emulated(s, v, p_dtype)
     else:
         p = torch.softmax(s, dim=-1)
         a = p @ v
@@ -324,8 +344,7 @@ def _encoder_layer_fold(x: torch.Tensor, sd, i: int, cfg) -> torch.Tensor:
                             sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], cfg.ln_eps, "w_qkv", _split("qkvw")), True, point="qkv")
     q, k, v = [t.reshape(b, n, cfg.heads, hd).transpose(1, 2) for t in qkv.split(d, dim=-1)]
     sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
-    e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
-    a = ((rnd(e, True, point="p") @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(b, n, d)
+    a = _pv_emulated(sc, v).transpose(1, 2).reshape(b, n, d)
     if _split("proj"):
         x = x + _split_product(a, sd[pre + "self_attention.out_proj.weight"].to(dt)) + _w(sd, pre + "self_attention.out_proj.bias", dt)
     else:
@@ -391,8 +410,7 @@ def encoder_layer_fp8(x: torch.Tensor, sd, i: int, cfg, scales4, mlp_only: bool 
     qkv = rnd(h @ q8_weight(sd, pre + "self_attention.in_proj_weight", dt).t() + _w(sd, pre + "self_attention.in_proj_bias", dt), True, torch.bfloat16)
     q, k, v = [t.reshape(b, n, cfg.heads, hd).transpose(1, 2) for t in qkv.split(d, dim=-1)]
     sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
-    e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
-    a = (rnd(e, True, torch.bfloat16) @ v) / e.sum(dim=-1, keepdim=True)
+    a = _pv_emulated(sc, v, torch.bfloat16, point=None)
     a = q8_act(a.transpose(1, 2).reshape(b, n, d), s_att)
     x = x + a @ q8_weight(sd, pre + "self_attention.out_proj.weight", dt).t() + _w(sd, pre + "self_attention.out_proj.bias", dt)
     h = q8_act(layer_norm(x, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps), s_h2)
@@ -417,8 +435,7 @@ def fp8_calibration_scales(x: torch.Tensor, sd, cfg):
         qkv = rnd(h1 @ _w(sd, pre + "self_attention.in_proj_weight", dt, True).t() + _w(sd, pre + "self_attention.in_proj_bias", dt), True)
         q, k, v = [z.reshape(b, n, cfg.heads, cfg.head_dim).transpose(1, 2) for z in qkv.split(d, dim=-1)]
         sc = (q @ k.transpose(-1, -2)) / math.sqrt(cfg.head_dim)
-        e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
-        a = rnd(((rnd(e, True) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(b, n, d), True)
+        a = rnd(_pv_emulated(sc, v, point=None).transpose(1, 2).reshape(b, n, d), True)
         t2 = t + att_in
         h2 = rnd(layer_norm(t2, _w(sd, pre + "ln_2.weight", dt), _w(sd, pre + "ln_2.bias", dt), cfg.ln_eps), True)
         u = rnd(gelu_erf(h2 @ _w(sd, pre + "mlp.0.weight", dt, True).t() + _w(sd, pre + "mlp.0.bias", dt)), True)

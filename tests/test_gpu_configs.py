@@ -221,6 +221,9 @@ def run_config(model, batch, precision, expect_gemm, expect_fold, layers_to_chec
             print(f"{model} B={batch} {precision} layer {layer}: " + ", ".join(sorted(kern)))
             for role, name in expect_gemm.items():
                 assert f"{role}:{name}" in kern, (role, name, sorted(kern))
+            # the attention kernel the oracle's rounding-aware evaluation assumes for this token count (oracle.engine_attention_form)
+            att = "ivit_attention_q32" if vo.engine_attention_form(cfg.tokens, cfg.head_dim) == "q32" else "ivit_attention_bf16"
+            assert f"attention:{att}" in kern, (att, sorted(kern))
             n_ln = sum(v["launches"] for k, v in kern.items() if k.startswith("layernorm"))
             assert n_ln == (1 if expect_fold else 2), kern       # fold: only the row statistics of the layer's input
             assert torch.equal(out, eng.run_node(f"encoder.layers.{layer}", tok_gpu)), "not deterministic"
@@ -253,7 +256,7 @@ def test_config2_vit_b16_batch64_as_dispatched():
 
 def test_config3_vit_l16_384_batch128_as_dispatched():
     """BASELINE configs[2]: 73 856 token rows - every encoder GEMM on the staggered 256x256 tile with the classic
-    epilogues, LayerNorm as a kernel, attention over 577 keys."""
+    epilogues, LayerNorm as a kernel, attention over 577 keys by the 32-query tiled kernel (ivit_attention_q32; asserted in run_config)."""
     k = "ivit_gemm_bf16_256x256x64_stag"     # "_f32": the f32-output epilogues (residual add) are their own instantiations since round 4
     run_config("vit_l_16_384", 128, "bf16", {"qkv": k, "proj": k + "_f32", "mlp1": k, "mlp2": k + "_f32"},
                expect_fold=False, layers_to_check=(0, 23), layer_tol=1e-3)
