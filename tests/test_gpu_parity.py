@@ -316,6 +316,95 @@ def test_vit_l16_384_long_sequence():
         eng.close()
 
 
+@pytest.mark.parametrize("image,tokens", [(384, 577), (368, 530), (272, 290)])
+@pytest.mark.parametrize("precision", ["bf16", "f16", "f16x", "fp8", "fp8m"])
+def test_long_sequence_attention_kernel_every_precision(image, tokens, precision):
+    """ivit_attention_q32 (32-query tiled kernel, >= 289 tokens at head dim 64) through every output form it has - 16-bit (bf16 / f16),
+    high + low parts for the split out-projection (f16x), e4m3 (fp8) - on a two-head model with ViT-L/16-384's token count (19 query blocks
+    on 16 waves: three leftover blocks shared by groups of waves through LDS), with 530 tokens (17 blocks: the one leftover block shared by
+    all 16 waves, partials filling LDS to the byte) and 290 (10 blocks, 10 waves, nothing left over).  Each layer node alone against the oracle
+    with the engine's rounding points (which evaluates this kernel's arithmetic: integer reference exponent, row sum of rounded numerators)."""
+    from interactive_vit_amd.engine import Engine
+    from oracle import vit_oracle
+    cfg = small_config(name=f"vit_test_long{tokens}", image=image, patch=16, dim=128, heads=2, layers=2, mlp=256, classes=16)
+    assert cfg.tokens == tokens and cfg.head_dim == 64 and vit_oracle.engine_attention_form(cfg.tokens, cfg.head_dim) == "q32"
+    sd = init_weights(cfg, seed=11, mode="rich")
+    eng = Engine(cfg, sd, device=0, max_batch=2, precision=precision)
+    try:
+        vit_oracle.OPERAND_DTYPE = eng.operand_dtype
+        vit_oracle.SPLIT_GEMMS = eng.split_gemms
+        vit_oracle.LN_FOLD = eng.ln_fold
+        x = synthetic_images(2, cfg, seed=17)
+        scales = eng.calibrate_fp8(x) if precision in ("fp8", "fp8m") else None
+        acts = vit_oracle.forward(x, sd, cfg, keep=True)
+        order = vit_oracle.node_suffixes(cfg)
+        for i in range(cfg.layers):
+            node_in = acts[order[order.index(f"encoder.layers.{i}") - 1]]
+            eng.profile(True); eng.profile_reset()
+            got = eng.run_node(f"encoder.layers.{i}", node_in.cuda()).cpu()
+            kern = eng.profile_kernels()
+            eng.profile(False)
+            assert "attention:ivit_attention_q32" in kern, sorted(kern)
+            if scales:
+                emu = vit_oracle.encoder_layer_fp8(node_in.double(), sd, i, cfg, scales[4 * i:4 * i + 4], mlp_only=precision == "fp8m")
+                tol = FP8_NODE_TOL
+            else:
+                emu = vit_oracle.run_node(f"encoder.layers.{i}", node_in.double(), sd, cfg, emulate=True)
+                tol = REL_TOL
+            err, e32 = rel_err(got, emu), rel_err(got, acts[f"encoder.layers.{i}"])
+            print(f"{cfg.name} {precision} encoder.layers.{i} alone vs rounding-aware oracle {err:.2e}, vs plain f32 {e32:.2e}")
+            assert err <= tol, (i, err)
+            assert torch.isfinite(got).all()
+            assert torch.equal(got, eng.run_node(f"encoder.layers.{i}", node_in.cuda()).cpu())
+        if precision in ("f16", "f16x"):
+            logits = eng.forward(x.cuda(), 0, len(eng.stages)).cpu()
+            assert rel_err(logits, acts["logits"]) <= F16_VS_F32_NODE
+    finally:
+        vit_oracle.OPERAND_DTYPE = torch.bfloat16
+        vit_oracle.SPLIT_GEMMS = frozenset()
+        eng.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_long_sequence_attention_redo_when_a_late_key_dominates(precision):
+    """ivit_attention_q32 takes its reference exponent from the first 32 keys a wave sees and never rescales; a numerator that leaves the
+    16-bit (or f32) range shows up as a non-finite row sum and the block is redone with the rows' true maximum.  Here key 100 scores ~ 200
+    nats above everything in the first tile for every query (weights built for it): the output must be finite and equal the oracle's."""
+    from interactive_vit_amd.engine import Engine
+    from oracle import vit_oracle
+    cfg = small_config(name="vit_test_long290", image=272, patch=16, dim=128, heads=2, layers=1, mlp=256, classes=16)
+    sd = init_weights(cfg, seed=12, mode="rich")
+    pre = "encoder.layers.encoder_layer_0."
+    d, hd, jstar = cfg.dim, cfg.head_dim, 100
+    w_in, b_in = sd[pre + "self_attention.in_proj_weight"].clone(), sd[pre + "self_attention.in_proj_bias"].clone()
+    w_in[: 2 * d] = 0
+    b_in[: 2 * d] = 0
+    b_in[:d] = 40.0 / 8.0                      # q = 5 in every component: q . k = 40 sum(k) / 8 ...
+    w_in[d: 2 * d, 0] = 4.0 / 8.0              # ... k = h[0] / 2 in every component: score = 40 x 4 x h[0] / 8 = 20 h[0] nats
+    sd[pre + "self_attention.in_proj_weight"], sd[pre + "self_attention.in_proj_bias"] = w_in, b_in
+    sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"] = torch.ones(d), torch.zeros(d)
+    g = torch.Generator().manual_seed(3)
+    tok = torch.randn(2, cfg.tokens, d, generator=g)
+    tok[:, jstar, 0] += 60.0                   # LayerNorm leaves h[jstar][0] ~ 11: 220 nats against |20 h[0]| <~ 70 elsewhere
+    eng = Engine(cfg, sd, device=0, max_batch=2, precision=precision)
+    try:
+        vit_oracle.OPERAND_DTYPE = eng.operand_dtype
+        vit_oracle.SPLIT_GEMMS = eng.split_gemms
+        vit_oracle.LN_FOLD = eng.ln_fold
+        probs = vit_oracle.attention_map(tok.double(), sd, 0, cfg)
+        assert float(probs[:, :, :, jstar].min()) > 0.999     # the construction does what it says
+        got = eng.run_node("encoder.layers.0", tok.cuda()).cpu()
+        assert torch.isfinite(got).all()
+        emu = vit_oracle.run_node("encoder.layers.0", tok.double(), sd, cfg, emulate=True)
+        err = rel_err(got, emu)
+        print(f"{cfg.name} {precision}: late dominant key, layer vs rounding-aware oracle {err:.2e}")
+        assert err <= REL_TOL
+    finally:
+        vit_oracle.OPERAND_DTYPE = torch.bfloat16
+        vit_oracle.SPLIT_GEMMS = frozenset()
+        eng.close()
+
+
 def test_attention_map_nodes(small):
     """`encoder.layers.<i>.attn`: [N,D] -> [heads,N,N] attention probabilities."""
     from oracle import vit_oracle
