@@ -40,7 +40,7 @@ static int fail(const char* fmt, ...) {
 extern "C" const char* ivit_last_error(void) { return t_last_error.c_str(); }
 extern "C" int ivit_abi_version(void) { return IVIT_ABI_VERSION; }
 extern "C" const char* ivit_build_info(void) {
-    return "libivit gfx950 (MI355X/CDNA4) bf16/f16/fp8-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_{128x128,160x128,256x256}x64, ivit_gemm_fp8_{128x128,160x128,256x256}x128, ivit_attention_bf16, "
+    return "libivit gfx950 (MI355X/CDNA4) bf16/f16/fp8-MFMA 16x16x32; kernels: " "ivit_gemm_bf16_{128x128,160x128,256x256}x64, ivit_gemm_fp8_{128x128,160x128,256x256}x128, ivit_attention_bf16, ivit_attention_q32, "
            "ivit_layernorm, ivit_unfold, ivit_tokens, ivit_transform";
 }
 

@@ -15,7 +15,7 @@ if [ "$1" != "gemm" ]; then
     hipcc $F fused_bench.hip $C/kernels_gemm.hip $C/kernels_attn.hip -o fused_bench.bin &
     # the whole engine with every study variant compiled in (IVIT_LIB=tools/libivit_abl.so python bench.py ...: in-situ A/B through the env knobs of kernels_gemm.hip)
     hipcc $F -fPIC -shared $C/engine.hip $C/kernels_gemm.hip $C/kernels_attn.hip $C/kernels_misc.hip -o libivit_abl.so -Wl,-rpath,/opt/rocm/lib &
-    for probe in mfma_peak mfma_pattern mfma_f8_probe permlane_probe dma_l1_probe; do   # single-file hardware probes
+    for probe in mfma_peak mfma_pattern mfma_f8_probe permlane_probe dma_l1_probe simd_share_probe; do   # single-file hardware probes
         [ -f $probe.bin ] && [ $probe.bin -nt $probe.hip ] || hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result $probe.hip -o $probe.bin
     done
 fi
