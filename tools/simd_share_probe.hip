@@ -52,7 +52,7 @@ __device__ __forceinline__ void role_loop(int iters, float* sink) {
         if (ROLE == 5) { M32(a0); FMA8(v); M32(a0); FMA8(v); M32(a0); FMA8(v); M32(a0); FMA8(v); M32(a0); FMA8(v); M32(a0); FMA8(v); M32(a0); FMA8(v); M32(a0); FMA8(v); }
         if (ROLE == 6) { M32(a0); FMA8(v); FMA8(v); M32(a0); FMA8(v); FMA8(v); M32(a0); FMA8(v); FMA8(v); M32(a0); FMA8(v); FMA8(v);
                          M32(a0); FMA8(v); FMA8(v); M32(a0); FMA8(v); FMA8(v); M32(a0); FMA8(v); FMA8(v); M32(a0); FMA8(v); FMA8(v); }
-        if (ROLE >= 20) {   // the attention step's mix: 16 x (fma, exp), 8 cvt_pk, 8 dot2c, 8 max3 [+ 8 MFMAs interleaved: 21+] [+ 12 LDS reads: 22+] [23: MFMAs in one burst]
+        if (ROLE >= 20 && ROLE <= 26) {   // the attention step's mix: 16 x (fma, exp), 8 cvt_pk, 8 dot2c, 8 max3 [+ 8 MFMAs interleaved: 21+] [+ 12 LDS reads: 22+] [23: MFMAs in one burst]
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 if (ROLE == 21 || ROLE == 22) { if (g & 1) M32(a1); else M32(a0); }
@@ -76,6 +76,30 @@ __device__ __forceinline__ void role_loop(int iters, float* sink) {
                                                                    : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(pkr)); }
         if (ROLE == 32) { for (int g = 0; g < 16; ++g) asm volatile("v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %1, %1, %5, %6\n v_max3_f32 %2, %2, %6, %7\n v_max3_f32 %3, %3, %7, %4\n"
                                                                    : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3])); }
+        if (ROLE == 33) {   // v_fma_f32 with three DISTINCT source registers and a fourth destination (64 per iteration)
+            for (int g = 0; g < 16; ++g) asm volatile("v_fma_f32 %0, %4, %5, %6\n v_fma_f32 %1, %5, %6, %7\n v_fma_f32 %2, %6, %7, %4\n v_fma_f32 %3, %7, %4, %5\n"
+                                                       : "=v"(e[0]), "=v"(e[1]), "=v"(e[2]), "=v"(e[3]) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        }
+        if (ROLE == 34) {   // 8 MFMAs over four accumulators AND rotating operand fragments (the kernel's register traffic: 24 source + 16 result registers each)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n v_mfma_f32_32x32x16_bf16 %1, %6, %7, %1\n v_mfma_f32_32x32x16_bf16 %2, %5, %6, %2\n v_mfma_f32_32x32x16_bf16 %3, %7, %4, %3\n"
+                         "v_mfma_f32_32x32x16_bf16 %0, %6, %4, %0\n v_mfma_f32_32x32x16_bf16 %1, %7, %5, %1\n v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n v_mfma_f32_32x32x16_bf16 %3, %5, %6, %3\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]));
+        }
+#define MR(acc, A, B) "v_mfma_f32_32x32x16_bf16 %" #acc ", %" #A ", %" #B ", %" #acc "\n"
+#define MS(acc, A, B) "v_mfma_f32_16x16x32_bf16 %" #acc ", %" #A ", %" #B ", %" #acc "\n"
+        // operands: %0..%3 accumulators, %4 %6 = ra[0] ra[1], %5 %7 = rb[0] rb[1], %8 %9 = ra[2] rb[2]
+        if (ROLE == 35) asm volatile(MR(0, 4, 5) MR(1, 6, 5) MR(2, 8, 5) MR(3, 4, 5) MR(0, 6, 5) MR(1, 8, 5) MR(2, 4, 5) MR(3, 6, 5)   // A rotates, B constant
+                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
+        if (ROLE == 36) asm volatile(MR(0, 4, 5) MR(1, 4, 7) MR(2, 4, 9) MR(3, 4, 5) MR(0, 4, 7) MR(1, 4, 9) MR(2, 4, 5) MR(3, 4, 7)   // A constant, B rotates
+                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
+        if (ROLE == 37) asm volatile(MS(0, 4, 5) MS(1, 6, 7) MS(2, 8, 9) MS(3, 4, 7) MS(0, 6, 9) MS(1, 8, 5) MS(2, 4, 9) MS(3, 6, 5)   // 16x16x32, both rotate
+                                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
+        if (ROLE == 38) asm volatile(MR(0, 4, 5) MR(1, 4, 5) MR(2, 6, 7) MR(3, 6, 7) MR(0, 8, 9) MR(1, 8, 9) MR(2, 4, 7) MR(3, 4, 7)   // both rotate, every pair used twice in a row
+                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
+        if (ROLE == 39) asm volatile(MR(0, 4, 5) MR(1, 6, 5) MR(2, 8, 7) MR(3, 4, 7) MR(0, 6, 9) MR(1, 8, 9) MR(2, 4, 5) MR(3, 6, 5)   // A rotates, B changes every second MFMA (P.V: one P, two V^T)
+                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
+        if (ROLE == 40) asm volatile(MR(0, 4, 5) MR(0, 6, 7) MR(0, 8, 9) MR(0, 4, 7) MR(1, 6, 9) MR(1, 8, 5) MR(1, 4, 9) MR(1, 6, 5)   // both rotate, chains of four on one accumulator (QK^T)
+                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
         if (ROLE == 8) { M16(c0); M16(c0); M16(c0); M16(c0); M16(c0); M16(c0); M16(c0); M16(c0); }
         if (ROLE == 9) { M16(c0); M16(c1); M16(c2); M16(c3); M16(c0); M16(c1); M16(c2); M16(c3); }
     }
@@ -115,9 +139,9 @@ __global__ __launch_bounds__(1024) void probe4(int iters, float* sink, unsigned 
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) clocks[wave] = t1 - t0;
 }
 
-static const char* names[27] = {"idle", "dep 32x32x16 chain", "2 accumulators", "v_fma stream", "v_exp stream", "dep chain + 8 fma / MFMA", "dep chain + 16 fma / MFMA",
+static const char* names[35] = {"idle", "dep 32x32x16 chain", "2 accumulators", "v_fma stream", "v_exp stream", "dep chain + 8 fma / MFMA", "dep chain + 16 fma / MFMA",
                                 "4 accumulators", "dep 16x16x32 chain", "4-acc 16x16x32", "", "", "", "", "", "", "", "", "", "",
-                                "step VALU mix (56)", "step mix + 8 MFMA", "step mix + 8 MFMA + 12 LDS", "step mix, MFMAs in a burst", "", "", "mix + MFMA + LDS, random data"};
+                                "step VALU mix (56)", "step mix + 8 MFMA", "step mix + 8 MFMA + 12 LDS", "step mix, MFMAs in a burst", "", "", "mix + MFMA + LDS, random data", "", "", "", "", "", "", "v_fma, 3 distinct sources", "MFMA, 4 acc, rotating operands"};
 template <int RA, int RB>
 void run(float* sink, unsigned long long* dclk) {
     const int iters = 4000;
@@ -160,5 +184,14 @@ int main() {
     run4<1, 4, 0, 0>("MFMA chain + v_exp", sink, dclk); run4<1, 4, 4, 4>("MFMA chain + 3 x v_exp", sink, dclk); run4<1, 3, 3, 3>("MFMA chain + 3 x v_fma", sink, dclk);
     run4<20, 20, 20, 20>("step VALU mix x4", sink, dclk); run4<21, 21, 21, 21>("step mix + 8 MFMA x4", sink, dclk); run4<26, 26, 26, 26>("step mix + 8 MFMA + 12 LDS x4", sink, dclk);
     run4<23, 23, 23, 23>("step mix, MFMAs in a burst x4", sink, dclk);
+    run4<33, 0, 0, 0>("v_fma (3 distinct sources) x1", sink, dclk); run4<33, 33, 33, 33>("v_fma (3 distinct sources) x4", sink, dclk);
+    run4<34, 0, 0, 0>("MFMA 4 acc, rotating operands x1", sink, dclk); run4<34, 34, 0, 0>("MFMA rotating x2", sink, dclk);
+    run4<34, 33, 33, 33>("MFMA rotating + 3 x v_fma distinct", sink, dclk); run4<1, 33, 33, 33>("MFMA chain + 3 x v_fma distinct", sink, dclk);
+    run4<34, 4, 4, 4>("MFMA rotating + 3 x v_exp", sink, dclk); run4<34, 30, 30, 30>("MFMA rotating + 3 x v_cvt_pk", sink, dclk);
+    run4<34, 34, 33, 33>("2 x MFMA rotating + 2 x v_fma distinct", sink, dclk);
+    run4<35, 0, 0, 0>("32x32x16: A rotates, B constant", sink, dclk); run4<36, 0, 0, 0>("32x32x16: A constant, B rotates", sink, dclk);
+    run4<37, 0, 0, 0>("16x16x32: A and B rotate", sink, dclk); run4<38, 0, 0, 0>("32x32x16: A and B rotate, each pair twice in a row", sink, dclk);
+    run4<39, 0, 0, 0>("32x32x16: A rotates, B every second", sink, dclk); run4<40, 0, 0, 0>("32x32x16: both rotate, chains of 4 on one accumulator", sink, dclk);
+    run4<35, 35, 0, 0>("A rotates x2", sink, dclk); run4<37, 37, 0, 0>("16x16x32 both rotate x2", sink, dclk);
     return 0;
 }
