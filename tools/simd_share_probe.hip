@@ -100,6 +100,14 @@ __device__ __forceinline__ void role_loop(int iters, float* sink) {
                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
         if (ROLE == 40) asm volatile(MR(0, 4, 5) MR(0, 6, 7) MR(0, 8, 9) MR(0, 4, 7) MR(1, 6, 9) MR(1, 8, 5) MR(1, 4, 9) MR(1, 6, 5)   // both rotate, chains of four on one accumulator (QK^T)
                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
+        if (ROLE == 41) {   // 512 v_fma_f32 in a straight line (4 KiB of code per iteration)
+#pragma unroll
+            for (int g = 0; g < 64; ++g) FMA8(v);
+        }
+        if (ROLE == 42) {   // 2048 v_fma_f32 in a straight line (16 KiB per iteration)
+#pragma unroll
+            for (int g = 0; g < 256; ++g) FMA8(v);
+        }
         if (ROLE == 8) { M16(c0); M16(c0); M16(c0); M16(c0); M16(c0); M16(c0); M16(c0); M16(c0); }
         if (ROLE == 9) { M16(c0); M16(c1); M16(c2); M16(c3); M16(c0); M16(c1); M16(c2); M16(c3); }
     }
@@ -189,6 +197,8 @@ int main() {
     run4<34, 33, 33, 33>("MFMA rotating + 3 x v_fma distinct", sink, dclk); run4<1, 33, 33, 33>("MFMA chain + 3 x v_fma distinct", sink, dclk);
     run4<34, 4, 4, 4>("MFMA rotating + 3 x v_exp", sink, dclk); run4<34, 30, 30, 30>("MFMA rotating + 3 x v_cvt_pk", sink, dclk);
     run4<34, 34, 33, 33>("2 x MFMA rotating + 2 x v_fma distinct", sink, dclk);
+    run4<41, 0, 0, 0>("512 v_fma straight line x1 (cycles per 64: divide by 8)", sink, dclk); run4<41, 41, 41, 41>("512 v_fma straight line x4 (divide by 8)", sink, dclk);
+    run4<42, 0, 0, 0>("2048 v_fma straight line x1 (divide by 32)", sink, dclk); run4<42, 42, 42, 42>("2048 v_fma straight line x4 (divide by 32)", sink, dclk);
     run4<35, 0, 0, 0>("32x32x16: A rotates, B constant", sink, dclk); run4<36, 0, 0, 0>("32x32x16: A constant, B rotates", sink, dclk);
     run4<37, 0, 0, 0>("16x16x32: A and B rotate", sink, dclk); run4<38, 0, 0, 0>("32x32x16: A and B rotate, each pair twice in a row", sink, dclk);
     run4<39, 0, 0, 0>("32x32x16: A rotates, B every second", sink, dclk); run4<40, 0, 0, 0>("32x32x16: both rotate, chains of 4 on one accumulator", sink, dclk);
