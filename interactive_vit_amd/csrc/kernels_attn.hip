@@ -393,7 +393,8 @@ __global__ __launch_bounds__(1024) void ivit_attention_pipe(AttnParams p, int it
 //              -> lane holds O[q][d = 32 dblk + (r & 3) + 8 (r >> 2) + 4 hi]
 // What was measured on the way (tools/attn_bench, tools/simd_share_probe; profiles/r04_attention_long.txt): a software-pipelined form with
 // two waves per SIMD (QK^T of tile t + 1 issued under the softmax of tile t, hand-placed MFMA / VALU interleave) ran at the same 300 - 320 us
-// per ViT-L launch as this one, which is the simpler code.  Both sit at ~1.7x the cycles a synthetic stream of the same instruction mix takes.
+// per ViT-L launch as this one, which is the simpler code.  The bound is the SIMD's one instruction stream: per 32 x 32 score tile the softmax's
+// 48 vector instructions cost ~240 cycles (v_exp_f32 8.2 each), an MFMA ~15 - 20 cycles of that stream besides its 32 in the pipe, an LDS read ~8.
 struct AttLayout32 {   // head dim 64: 128-B rows of 8 chunks; K chunk slot = ch ^ ((key >> 1) & 7) (ds_read_b128 by 32 keys x one chunk: conflict free),
     static constexpr int ROW = 128, TILE = 32 * ROW;   // V chunk slot = ch ^ (((key >> 1) & 1) << 2) (tr reads of 4 keys x 32 d per half wave: conflict free)
     static constexpr int K_SWZ = 0, V_SWZ = 1;
