@@ -692,6 +692,141 @@ __global__ __launch_bounds__(MAXW * 64) void ivit_attention_q32(AttnParams p, in
     store_block(qbase, 1.0f / (sa + sb));
 }
 
+#ifdef IVIT_GEMM_ABLATIONS   // study (tools/attn_bench, IVIT_ATT32=4): two query blocks (64 queries) per wave sharing every K / V fragment read, 8 waves;
+// whole units only (tokens a multiple of 64, at most 8 units) - a rate comparison against ivit_attention_q32, not a product kernel
+template <class OP>
+__global__ __launch_bounds__(512) void ivit_attention_q64_study(AttnParams p, int nt) {
+    using L = AttLayout32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rows = nt * 32;
+    char* k_lds = smem;
+    char* v_lds = smem + rows * L::ROW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int ql = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int N = p.tokens;
+    const int D = p.heads * 64;
+    const size_t row0 = (size_t)b * N;
+    const bf16_t* qkv = p.qkv;
+    const int ld = p.ldqkv;
+    att_stage32(k_lds, qkv + row0 * ld + h * 64 + D, ld, N, rows, L::K_SWZ, wave, nwaves, lane);
+    att_stage32(v_lds, qkv + row0 * ld + h * 64 + 2 * D, ld, N, rows, L::V_SWZ, wave, nwaves, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float cexp = p.scale * 1.44269504088896340736f;
+    typedef IVIT_LDS const char* lds_ptr;
+    lds_ptr kp[4], vp[2];
+    {
+        lds_ptr lds0 = (lds_ptr)smem;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kp[kk] = lds0 + ql * L::ROW + (((2 * kk + hi) ^ ((ql >> 1) & 7)) << 4);
+        const int gg = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk) {
+            const int c = 4 * dblk + 2 * (gg & 1) + (pp >> 1);
+            vp[dblk] = lds0 + rows * L::ROW + (4 * hi + q4) * L::ROW + ((c ^ ((q4 >> 1) << 2)) << 4) + (pp & 1) * 8;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(kp[kk]));
+        asm volatile("" : "+v"(vp[0]), "+v"(vp[1]));
+    }
+    const int qbase = wave * 64;
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qrow = min(qbase + 32 * u + ql, N - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[u][kk] = *reinterpret_cast<const bf16x8*>(qkv + (row0 + qrow) * ld + h * 64 + kk * 16 + hi * 8);
+    }
+    f32x16 o0[2], o1[2], s[2];
+    float m_row[2], sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[u][r] = 0.f; o1[u][r] = 0.f; }
+    auto qk = [&](int off) {
+        bf16x8 kf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<IVIT_LDS const bf16x8*>(kp[kk] + off);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s[0] = OP::mfma32(kf[kk], qf[0][kk], s[0]);
+            s[1] = OP::mfma32(kf[kk], qf[1][kk], s[1]);
+        }
+    };
+    qk(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float ta = fmaxf(fmaxf(s[u][0], s[u][1]), s[u][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) ta = fmaxf(fmaxf(ta, s[u][r]), s[u][r + 1]);
+        float xa, xb;
+        pair_exchange(fmaxf(ta, s[u][15]), xa, xb);
+        m_row[u] = ceilf(fmaxf(xa, xb) * cexp);
+    }
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+        union { bf16x8 v; bf16x4 h2[2]; } vf[2][2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int dblk = 0; dblk < 2; ++dblk) {
+                vf[st][dblk].h2[0] = lds_read_tr16(vp[dblk] + (16 * st) * L::ROW);
+                vf[st][dblk].h2[1] = lds_read_tr16(vp[dblk] + (16 * st + 8) * L::ROW);
+            }
+        union { bf16x8 v; unsigned int u[4]; } pk[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float nm = -m_row[u];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(s[u][r], cexp, nm));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(s[u][r + 1], cexp, nm));
+                const unsigned int pr = OP::pack2(e0, e1);
+                sum[u] = OP::add_pair(pr, sum[u]);
+                pk[u][r >> 3].u[(r & 7) >> 1] = pr;
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                o0[u] = OP::mfma32(vf[st][0].v, pk[u][st].v, o0[u]);
+                o1[u] = OP::mfma32(vf[st][1].v, pk[u][st].v, o1[u]);
+            }
+        qk(L::TILE);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) kp[kk] += L::TILE;
+        vp[0] += L::TILE; vp[1] += L::TILE;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float sa, sb;
+        pair_exchange(sum[u], sa, sb);
+        const float inv = 1.0f / (sa + sb);
+        const int q = qbase + 32 * u + ql;
+        bf16_t* orow = p.out + (row0 + q) * p.ldo + h * 64 + hi * 8;
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk)
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const f32x16& o = dblk ? o1[u] : o0[u];
+                const auto ra = __builtin_amdgcn_permlane32_swap(OP::pack2(o[4 * j] * inv, o[4 * j + 1] * inv), OP::pack2(o[4 * j + 4] * inv, o[4 * j + 5] * inv), false, false);
+                const auto rb = __builtin_amdgcn_permlane32_swap(OP::pack2(o[4 * j + 2] * inv, o[4 * j + 3] * inv), OP::pack2(o[4 * j + 6] * inv, o[4 * j + 7] * inv), false, false);
+                const u32x4 pkk = {ra[0], rb[0], ra[1], rb[1]};
+                if (q < N) *reinterpret_cast<u32x4*>(orow + dblk * 32 + j * 8) = pkk;
+            }
+    }
+}
+#endif
+
 template <class OP, int MAXW>
 static hipError_t launch_q32_op(const AttnParams& p, hipStream_t stream) {
     const int nt = ceil_div(p.tokens, 32);
@@ -760,7 +895,7 @@ static hipError_t launch_nkf(const AttnParams& p, hipStream_t stream) {
 }
 
 #ifdef IVIT_GEMM_ABLATIONS
-static int att32_force() { static const int force = [] { const char* v = getenv("IVIT_ATT32"); return v ? atoi(v) : -1; }(); return force; }   // study knob: 0 never, 1 whenever head dim 64, 2 the same with 12 waves
+static int att32_force() { static const int force = [] { const char* v = getenv("IVIT_ATT32"); return v ? atoi(v) : -1; }(); return force; }   // study knob: 0 never, 1 whenever head dim 64, 2 the same with 12 waves, 4 the 64-query study kernel (tokens a multiple of 64, <= 512)
 #endif
 // Which kernel: the 32-query tiled form from 289 tokens on at head dim 64 (measured at B x H = 2048 heads, tools/attn_bench: 257 tokens 88.6 us
 // against 90.5 for the one-pass form, 325 tokens 141 against 180, 417 tokens 212 against 268, 577 tokens 332 against 376; 197 tokens 51.6 against
@@ -780,6 +915,13 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     const int nkf = round_up(ceil_div(p.tokens, 16), 2);
     if (use_q32(p)) {
 #ifdef IVIT_GEMM_ABLATIONS
+        if (att32_force() == 4 && p.tokens % 64 == 0 && p.tokens <= 512 && !p.f16 && !p.out8 && !p.lo_off) {
+            const int nt = p.tokens / 32;
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ivit_attention_q64_study<OpBf16>), 2 * 19 * AttLayout32::TILE);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((ivit_attention_q64_study<OpBf16>), dim3(1, p.heads, p.batch), dim3((nt / 2) * 64), 2 * nt * AttLayout32::TILE, stream, p, nt);
+            return hipGetLastError();
+        }
         if (att32_force() == 2) return p.f16 ? launch_q32_op<OpF16, 12>(p, stream) : launch_q32_op<OpBf16, 12>(p, stream);
 #endif
         return p.f16 ? launch_q32_op<OpF16, 16>(p, stream) : launch_q32_op<OpBf16, 16>(p, stream);
