@@ -39,6 +39,9 @@ __device__ __forceinline__ void role_loop(int iters, float* sink) {
     float v[4] = {0.5f, 0.25f, 0.125f, 0.0625f};
     float e[4] = {0.1f, 0.2f, 0.3f, 0.4f}, tmx = 0.f;
     unsigned pkr = 0, pq[4] = {0, 0, 0, 0};
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    f2 pd[4], ps[4];
+    for (int i = 0; i < 4; ++i) { ps[i] = f2{0.5f + i, 0.25f * i}; pd[i] = f2{0.f, 0.f}; }
     typedef __attribute__((ext_vector_type(2))) unsigned u2; typedef __attribute__((ext_vector_type(4))) unsigned u4;
     u2 l2[8]; u4 l4[4];
     const unsigned laddr = (threadIdx.x & 63) * 16;
@@ -100,6 +103,14 @@ __device__ __forceinline__ void role_loop(int iters, float* sink) {
                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
         if (ROLE == 40) asm volatile(MR(0, 4, 5) MR(0, 6, 7) MR(0, 8, 9) MR(0, 4, 7) MR(1, 6, 9) MR(1, 8, 5) MR(1, 4, 9) MR(1, 6, 5)   // both rotate, chains of four on one accumulator (QK^T)
                                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(ra[0]), "v"(rb[0]), "v"(ra[1]), "v"(rb[1]), "v"(ra[2]), "v"(rb[2]));
+        if (ROLE == 43) {   // 64 v_pk_fma_f32 (two f32 lanes each), distinct sources
+            for (int g = 0; g < 16; ++g) asm volatile("v_pk_fma_f32 %0, %4, %5, %6\n v_pk_fma_f32 %1, %5, %6, %7\n v_pk_fma_f32 %2, %6, %7, %4\n v_pk_fma_f32 %3, %7, %4, %5\n"
+                                                       : "=v"(pd[0]), "=v"(pd[1]), "=v"(pd[2]), "=v"(pd[3]) : "v"(ps[0]), "v"(ps[1]), "v"(ps[2]), "v"(ps[3]));
+        }
+        if (ROLE == 44) {   // 64 v_pk_mul_f32
+            for (int g = 0; g < 16; ++g) asm volatile("v_pk_mul_f32 %0, %4, %5\n v_pk_mul_f32 %1, %5, %6\n v_pk_mul_f32 %2, %6, %7\n v_pk_mul_f32 %3, %7, %4\n"
+                                                       : "=v"(pd[0]), "=v"(pd[1]), "=v"(pd[2]), "=v"(pd[3]) : "v"(ps[0]), "v"(ps[1]), "v"(ps[2]), "v"(ps[3]));
+        }
         if (ROLE == 41) {   // 512 v_fma_f32 in a straight line (4 KiB of code per iteration)
 #pragma unroll
             for (int g = 0; g < 64; ++g) FMA8(v);
@@ -113,7 +124,7 @@ __device__ __forceinline__ void role_loop(int iters, float* sink) {
     }
     if (ROLE == 26) { v[0] = (float)ra[0][0]; v[1] = (float)rb[1][3]; v[2] = (float)ra[2][5]; }
     if (ROLE == 22 || ROLE == 26) v[0] += __builtin_bit_cast(float, l2[0][0] ^ l2[7][1] ^ l4[0][0] ^ l4[3][3]);
-    v[0] += __builtin_bit_cast(float, pq[0] ^ pq[1] ^ pq[2] ^ pq[3]);
+    v[0] += __builtin_bit_cast(float, pq[0] ^ pq[1] ^ pq[2] ^ pq[3]) + pd[0][0] + pd[1][1] + pd[2][0] + pd[3][1];
     float s = e[0] + e[1] + e[2] + e[3] + tmx + __builtin_bit_cast(float, pkr) + a0[0] + a1[3] + a2[5] + a3[7] + c0[0] + c1[1] + c2[2] + c3[3] + v[0] + v[1] + v[2] + v[3];
     if (s == 123.456f) sink[0] = s;
 }
@@ -197,6 +208,8 @@ int main() {
     run4<34, 33, 33, 33>("MFMA rotating + 3 x v_fma distinct", sink, dclk); run4<1, 33, 33, 33>("MFMA chain + 3 x v_fma distinct", sink, dclk);
     run4<34, 4, 4, 4>("MFMA rotating + 3 x v_exp", sink, dclk); run4<34, 30, 30, 30>("MFMA rotating + 3 x v_cvt_pk", sink, dclk);
     run4<34, 34, 33, 33>("2 x MFMA rotating + 2 x v_fma distinct", sink, dclk);
+    run4<43, 0, 0, 0>("v_pk_fma_f32 x1", sink, dclk); run4<43, 43, 43, 43>("v_pk_fma_f32 x4", sink, dclk); run4<1, 43, 43, 43>("MFMA chain + 3 x v_pk_fma_f32", sink, dclk);
+    run4<44, 0, 0, 0>("v_pk_mul_f32 x1", sink, dclk); run4<44, 44, 44, 44>("v_pk_mul_f32 x4", sink, dclk);
     run4<41, 0, 0, 0>("512 v_fma straight line x1 (cycles per 64: divide by 8)", sink, dclk); run4<41, 41, 41, 41>("512 v_fma straight line x4 (divide by 8)", sink, dclk);
     run4<42, 0, 0, 0>("2048 v_fma straight line x1 (divide by 32)", sink, dclk); run4<42, 42, 42, 42>("2048 v_fma straight line x4 (divide by 32)", sink, dclk);
     run4<35, 0, 0, 0>("32x32x16: A rotates, B constant", sink, dclk); run4<36, 0, 0, 0>("32x32x16: A constant, B rotates", sink, dclk);
