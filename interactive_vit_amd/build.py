@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB_PATH = os.path.join(HERE, "libivit.so")
-SOURCES = ["engine.hip", "kernels_gemm.hip", "kernels_attn.hip", "kernels_misc.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_kernel.h", "gemm256_kernel.h", "gemm256s_kernel.h",  os.path.join("..", "..", "include", "ivit.h")]
+SOURCES = ["engine.hip", "kernels_gemm.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_mlp.hip"]
+HEADERS = ["common.h", "kernels.h", "gemm_kernel.h", "gemm256_kernel.h", "gemm256s_kernel.h", "mlp_fused_kernel.h", os.path.join("..", "..", "include", "ivit.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    with ThreadPoolExecutor(max_workers=5) as pool:
         objs = list(pool.map(compile_one, SOURCES))
     link = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH, *objs,
             "-Wl,-rpath,/opt/rocm/lib", "-Wl,-soname,libivit.so"]

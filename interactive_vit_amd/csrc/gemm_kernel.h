@@ -669,38 +669,38 @@ __device__ __forceinline__ void ln_chan_update(float& mean, float& m2, float sm,
     }
 }
 
+// (mean, rstd) of ONE row from the per-64-column (sum, M2) pairs a residual GEMM left for it, folded in slot order.  Every consumer of the
+// pairs goes through this function (ln_tile_stats of the _lf GEMMs, the fused MLP kernel): the same bits whoever folds them.
+__device__ __forceinline__ float2 ln_row_stats_from_pairs(const float2* ln_part, int m, int ln_dim, float ln_eps, const float4* first = nullptr) {
+    const int nslots = (ln_dim + 63) >> 6;
+    const float4* pr = reinterpret_cast<const float4*>(ln_part + (size_t)m * GEMM_LN_SLOTS);
+    float mean = 0.f, m2 = 0.f;
+    // Chan's update for slot k (0-based) when every earlier slot is a full 64 columns:
+    //   d = mean_k - mean;  mean += d * n_k / (64 k + n_k);  M2 += M2_k + d^2 * 64 k n_k / (64 k + n_k)
+    // fully unrolled, so for the full slots (n_k = 64) the three ratios are compile-time constants - the
+    // loop with run-time divisions cost the MLP-up GEMM 7 us at the start of its tiles
+#pragma unroll
+    for (int s0 = 0; s0 < GEMM_LN_SLOTS; s0 += 12) {
+        if (s0 >= nslots) break;                      // uniform
+        float4 raw[6];
+#pragma unroll
+        for (int l = 0; l < 6; ++l) raw[l] = (s0 == 0 && first) ? first[l] : pr[min((s0 >> 1) + l, GEMM_LN_SLOTS / 2 - 1)];   // the first 12 slots may have been loaded ahead (ln_tile_stats_prefetch)
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int s2 = s0 + q;                     // compile-time after unrolling
+            if (s2 >= GEMM_LN_SLOTS || s2 >= nslots) continue;
+            const float sm = (q & 1) ? raw[q >> 1].z : raw[q >> 1].x, mm = (q & 1) ? raw[q >> 1].w : raw[q >> 1].y;
+            ln_chan_update(mean, m2, sm, mm, s2, ln_dim);
+        }
+    }
+    return make_float2(mean, 1.0f / sqrtf(m2 / (float)ln_dim + ln_eps));
+}
+
 template <class T>
 __device__ __forceinline__ void ln_tile_stats(const GemmParams& p, int m0, float2* tile_stats, const float4* first = nullptr) {
     for (int r = threadIdx.x; r < T::BM; r += T::THREADS) {
         const int m = min(m0 + r, p.M - 1);     // rows past M: a valid row's statistics (their outputs are never stored)
-        float2 st;
-        if (p.ln_stats) {
-            st = p.ln_stats[m];
-        } else {
-            const int nslots = (p.ln_dim + 63) >> 6;
-            const float4* pr = reinterpret_cast<const float4*>(p.ln_part + (size_t)m * GEMM_LN_SLOTS);
-            float mean = 0.f, m2 = 0.f;
-            // Chan's update for slot k (0-based) when every earlier slot is a full 64 columns:
-            //   d = mean_k - mean;  mean += d * n_k / (64 k + n_k);  M2 += M2_k + d^2 * 64 k n_k / (64 k + n_k)
-            // fully unrolled, so for the full slots (n_k = 64) the three ratios are compile-time constants - the
-            // loop with run-time divisions cost the MLP-up GEMM 7 us at the start of its tiles
-#pragma unroll
-            for (int s0 = 0; s0 < GEMM_LN_SLOTS; s0 += 12) {
-                if (s0 >= nslots) break;                      // uniform
-                float4 raw[6];
-#pragma unroll
-                for (int l = 0; l < 6; ++l) raw[l] = (s0 == 0 && first) ? first[l] : pr[min((s0 >> 1) + l, GEMM_LN_SLOTS / 2 - 1)];   // the first 12 slots may have been loaded ahead (ln_tile_stats_prefetch)
-#pragma unroll
-                for (int q = 0; q < 12; ++q) {
-                    const int s2 = s0 + q;                     // compile-time after unrolling
-                    if (s2 >= GEMM_LN_SLOTS || s2 >= nslots) continue;
-                    const float sm = (q & 1) ? raw[q >> 1].z : raw[q >> 1].x, mm = (q & 1) ? raw[q >> 1].w : raw[q >> 1].y;
-                    ln_chan_update(mean, m2, sm, mm, s2, p.ln_dim);
-                }
-            }
-            st = make_float2(mean, 1.0f / sqrtf(m2 / (float)p.ln_dim + p.ln_eps));
-        }
-        tile_stats[r] = st;
+        tile_stats[r] = p.ln_stats ? p.ln_stats[m] : ln_row_stats_from_pairs(p.ln_part, m, p.ln_dim, p.ln_eps, first);
     }
 }
 
