@@ -169,6 +169,7 @@ struct LayerWeights {
     // LayerNorm folded into the GEMM that consumes it: W' = W . diag(gamma) (bf16), s = row sums of W', c = W beta + b
     Matrix wf_in, wf_1;
     float *s_in = nullptr, *c_in = nullptr, *s_1 = nullptr, *c_1 = nullptr;
+    bf16_t* wp_mlp = nullptr;   // fused MLP (kernels_mlp.hip): wf_1 and w2 in the kernel's fragment-native stream order
     float s_h1 = 1.f, s_att = 1.f, s_h2 = 1.f, s_u = 1.f;   // static activation scales (calibrated)
 };
 
@@ -235,6 +236,7 @@ struct ivit_engine {
     // LayerNorm fold (bf16 data path; IVIT_FOLD_LN=0 keeps the LayerNorm kernel): see run_layer
     uint64_t stats_token = 0; int stats_batch = 0;   // resident_token of the host-call output whose LayerNorm statistics pairs / 16-bit copy are in the workspace
     bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
+    bool fused_mlp = false;         // LN2 -> MLP up -> GELU -> MLP down -> residual in ONE launch where the shape allows (IVIT_FUSED_MLP=0 switches it off)
     bool fold_blocked = false;      // ivit_ln_fold_calibrate found rows with |mean| / std above its threshold: keep the LayerNorm kernels
     float* ratio_dev = nullptr;     // calibration scratch: max |mean| / std seen (non-null only while calibrating)
     float* ratio_scratch = nullptr; // its device word, allocated once at ivit_create
@@ -391,6 +393,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         const char* fl = getenv("IVIT_FOLD_LN");
         e->fold_ln = !(fl && atoi(fl) == 0) && !precision_is_fp8(cfg->precision) && cfg->dim <= 64 * GEMM_LN_SLOTS;
         e->fold_always = fl && atoi(fl) == 2;
+        const char* fm = getenv("IVIT_FUSED_MLP");
+        e->fused_mlp = e->fold_ln && !(fm && atoi(fm) == 0) && mlp_fused_supported(1, cfg->dim, cfg->mlp, e->f16, e->f16x ? 1 : 0);
         if (e->split < 1 || e->split > ivit_engine::MAX_SPLIT) e->split = 1;
         for (int i = 0; i < ivit_engine::MAX_SPLIT; ++i) {
             if (hipStreamCreateWithFlags(&e->aux_stream[i], hipStreamNonBlocking) != hipSuccess ||
@@ -420,6 +424,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         if (e->fold_ln) {
             chk(alloc_matrix(e, &lw.wf_in, 3 * D, D)); chk(alloc_vec(e, &lw.s_in, 3 * D)); chk(alloc_vec(e, &lw.c_in, 3 * D));
             chk(alloc_matrix_split(e, &lw.wf_1, Mlp, D, e->f16x ? 1 : 0)); chk(alloc_vec(e, &lw.s_1, Mlp)); chk(alloc_vec(e, &lw.c_1, Mlp));
+            if (e->fused_mlp) chk(dev_alloc(e, (void**)&lw.wp_mlp, mlp_fused_packed_bytes(D, Mlp, e->f16x ? 1 : 0), true));
         }
         if (rc) break;
     }
@@ -588,6 +593,7 @@ static int require_weights(ivit_engine* e) {
                 HIP_TRY(launch_split_weight(lw.w1.f32, lw.w1.cols, lw.w1.rows, lw.w1.cols, lw.ln2_g, lw.ln2_b, lw.b1, lw.wf_1.p, lw.wf_1.ld, lw.wf_1.kpad, 0, lw.s_1, lw.c_1, st, e->f16));
             else
                 HIP_TRY(launch_fold_ln_weights(lw.w1.p, lw.w1.ld, lw.w1.rows, lw.w1.cols, lw.ln2_g, lw.ln2_b, lw.b1, lw.wf_1.p, lw.s_1, lw.c_1, st, e->f16));
+            if (e->fused_mlp) HIP_TRY(launch_mlp_pack_weights(lw.wf_1.p, lw.wf_1.ld, lw.w2.p, lw.w2.ld, e->D, e->cfg.mlp, e->f16x ? 1 : 0, lw.wp_mlp, st));
         }
         HIP_TRY(hipStreamSynchronize(st));
         e->fold_ready = true;
@@ -734,6 +740,15 @@ static bool fold_for_rows(const ivit_engine* e, int M) {
     return e->fold_ln && !e->fold_blocked && (e->fold_always || !gemm_prefers_256(M, e->D, e->D));
 }
 
+// The fused MLP kernel runs one workgroup of 64 rows per CU: it takes the calls whose grids fill at least 70 % of the CU slots of their last round
+// (ViT-B/16: B = 64 -> 197 workgroups, B = 256 -> 788 = 3.08 rounds); below that - the interactive path - the GEMM pair on its small tiles is faster.
+static bool fused_mlp_for_rows(const ivit_engine* e, int M) {
+    if (!e->fused_mlp) return false;
+    static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
+    const int wgs = (M + 63) / 64, rounds = (wgs + cus - 1) / cus;
+    return 10 * wgs >= 7 * rounds * cus;
+}
+
 // bf16 layer; amax4 != nullptr (calibration): record max|.| of the four GEMM-input tensors.
 //
 // LayerNorm fold (e->fold_ln, the default on the bf16 data path): no LayerNorm kernel and no LayerNorm output
@@ -783,6 +798,19 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         if (run_gemm(e, st, w.att, e->ld_att, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, xi, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
         if (tap == TAP_PROJ || tap == TAP_H2) return 0;
         fold.s = lw.s_1;
+        if (tap != TAP_U && fused_mlp_for_rows(e, M)) {
+            // MLP up + GELU + MLP down + residual (+ the next layer's statistics pairs and 16-bit copy) in one launch: bit-identical to the two GEMM launches
+            // below (tests), the hidden tensor never leaves the CU.  (The TAP_U inspector takes the two-launch path: it wants the hidden tensor itself.)
+            MlpFusedParams mp{};
+            mp.X = w.h; mp.ldx = D; mp.ln_part_in = w.ln_part; mp.ln_eps = e->cfg.ln_eps; mp.Wp = lw.wp_mlp; mp.c1 = lw.c_1; mp.s1 = lw.s_1; mp.b2 = lw.b2;
+            mp.resid = w.x; mp.ldr = D; mp.out = xo; mp.ldo = D; mp.xb = w.h; mp.ldxb = D; mp.ln_part_out = w.ln_part;
+            mp.M = M; mp.D = D; mp.Mlp = Mlp; mp.f16 = e->f16; mp.split = e->f16x ? 1 : 0; mp.stats_out = stats_out ? 1 : 0;
+            const double flops = 4.0 * M * (double)D * Mlp;
+            const double bytes = 2.0 * M * D + 4.0 * D * Mlp * (e->f16x ? 2.0 : 1.0) + 8.0 * M * D + (stats_out ? 2.0 * M * D : 0.0);
+            ProfScope ps(e, PC_GEMM, st, flops, bytes, "mlp", mlp_fused_kernel_name(mp));
+            HIP_TRY(launch_mlp_fused(mp, st));
+            return 0;
+        }
         if (run_gemm(e, st, w.h, D, lw.wf_1, M, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "mlp1")) return 1;
         if (tap == TAP_U) return 0;
         if (stats_out) return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_STATS, xo, D, w.x, D, nullptr, 0, 0, 0, 0, &fold, "mlp2");

@@ -81,15 +81,14 @@ const char* gemm_fp8_kernel_name(const GemmParams& p);
 
 // ---------------------------------------------------------------- fused MLP (kernels_mlp.hip, mlp_fused_kernel.h)
 // One launch for LN2 (folded) -> MLP up -> GELU -> MLP down -> residual add (-> 16-bit copy + row statistics of the new rows): a workgroup owns 64
-// token rows and streams W1' / W2 once; the hidden activations never leave the CU.  Bit-identical to launch_gemm(EPI_LNFOLD_GELU_BF16)
-// followed by launch_gemm(EPI_BIAS_RESID_STATS / EPI_BIAS_RESID_F32) on the same operands.
+// token rows and streams both weight matrices once, straight from L2 into MFMA operand registers; the hidden activations never leave the CU.
+// Bit-identical to launch_gemm(EPI_LNFOLD_GELU_BF16) followed by launch_gemm(EPI_BIAS_RESID_STATS / EPI_BIAS_RESID_F32) on the same operands.
 struct MlpFusedParams {
     const bf16_t* X; int ldx;            // [M, D] 16-bit operand copy of the LayerNorm input rows (readable up to round_up(M, 64) rows)
     const float2* ln_part_in;            // [M][GEMM_LN_SLOTS] (sum, M2) pairs of those rows
     float ln_eps;
-    const bf16_t* W1; int ldw1;          // [Mlp, D] LayerNorm-folded up weight W . diag(gamma); split: hi / lo K-tiles interleaved, ldw1 = 2 D
+    const bf16_t* Wp;                    // both weight matrices in the kernel's fragment-native stream order (launch_mlp_pack_weights)
     const float* c1; const float* s1;    // [Mlp] fold vectors: c = W beta + b, s = row sums of W'
-    const bf16_t* W2; int ldw2;          // [D, Mlp] down weight; split: hi / lo K-tiles interleaved, ldw2 = 2 Mlp
     const float* b2;                     // [D]
     const float* resid; int ldr;         // [M, D] f32 residual rows
     float* out; int ldo;                 // [M, D] f32 (may alias resid)
@@ -97,11 +96,14 @@ struct MlpFusedParams {
     float2* ln_part_out;                 // stats_out: their pairs (may alias ln_part_in)
     int M, D, Mlp;
     int f16;                             // 0: bf16 operands, 1: IEEE f16
-    int split;                           // 0, or 1: W1 / W2 carry hi / lo pairs (IVIT_PRECISION_F16X)
+    int split;                           // 0, or 1: the weights are hi / lo pairs (IVIT_PRECISION_F16X)
     int stats_out;                       // 1: EPI_BIAS_RESID_STATS semantics, 0: EPI_BIAS_RESID_F32
     unsigned long long* stamps;          // microbenchmark builds only
 };
 bool mlp_fused_supported(int M, int D, int Mlp, int f16, int split);
+size_t mlp_fused_packed_bytes(int D, int Mlp, int split);
+// W1 [Mlp, D] (LayerNorm-folded up weight; split: hi / lo K-tiles interleaved, ldw1 >= 2 D), W2 [D, Mlp] (split: likewise, ldw2 >= 2 Mlp) -> out
+hipError_t launch_mlp_pack_weights(const bf16_t* W1, int ldw1, const bf16_t* W2, int ldw2, int D, int Mlp, int split, bf16_t* out, hipStream_t stream);
 hipError_t launch_mlp_fused(const MlpFusedParams& p, hipStream_t stream);
 const char* mlp_fused_kernel_name(const MlpFusedParams& p);
 

@@ -1,10 +1,11 @@
-// Instantiations and launcher of the fused MLP kernel (mlp_fused_kernel.h): LN2 (folded) -> up -> GELU -> down -> residual in one launch.
+// Instantiations and launchers of the fused MLP kernel (mlp_fused_kernel.h): LN2 (folded) -> up -> GELU -> down -> residual in one launch,
+// and the one-time re-layout of its two weight matrices into the fragment-native stream the kernel reads.
 #include "mlp_fused_kernel.h"
 #include <cstdlib>
 
 namespace ivit {
 
-// one workgroup of 8 waves per CU (160 KiB of LDS at D = 768; up to 256 VGPRs per lane)
+// one workgroup of 8 waves per CU (X + two U buffers in LDS: 128 KiB at D = 768; up to 256 VGPRs per lane)
 #define IVIT_MLPF_KERNEL(NAME, ND, SPLIT, OP)                                                 \
     __global__ __launch_bounds__(512, 2) void NAME(MlpFusedParams p) {                        \
         extern __shared__ __attribute__((aligned(16))) char smem[];                          \
@@ -18,12 +19,52 @@ IVIT_MLPF_KERNEL(ivit_mlp_fused_f16_d512, 8, 1, OpF16)
 IVIT_MLPF_KERNEL(ivit_mlp_fused_f16x_d512, 8, 2, OpF16)
 #undef IVIT_MLPF_KERNEL
 
-// D = 768 (ViT-B) and 512 (test models): X (D / 64 x 8 KiB) + the four-slot ring must fit the CU's 160 KiB of LDS, and a wave's share of the
-// [64, D] f32 accumulator (D / 8 registers) its register file.  The hidden width walks in chunks of 128; weight pairs only on the f16 path.
+// the stream: for chunk c (128 hidden), wave w, block b (mlpf_block_source), lane l: 8 consecutive k of one weight row - 16 bytes at
+// ((c * 8 + w) * CB + b) * 1024 + l * 16.  One thread per 16-byte unit.
+template <int ND, int SPLIT>
+__global__ __launch_bounds__(256) void ivit_mlp_pack_weights(const bf16_t* __restrict__ W1, int ldw1, const bf16_t* __restrict__ W2, int ldw2, int nchunks,
+                                                             bf16_t* __restrict__ out) {
+    using G = MlpFusedGeom<ND, SPLIT>;
+    const long long unit = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)nchunks * 8 * G::CB * 64;
+    if (unit >= total) return;
+    const int lane = (int)(unit & 63);
+    const long long blk = unit >> 6;
+    const int b = (int)(blk % G::CB), w = (int)((blk / G::CB) & 7), c = (int)(blk / (8 * G::CB));
+    bool is_w1; int row, col;
+    mlpf_block_source<ND, SPLIT>(c, w, b, lane, &is_w1, &row, &col);
+    const bf16_t* src = is_w1 ? W1 + (size_t)row * ldw1 + col : W2 + (size_t)row * ldw2 + col;
+    *reinterpret_cast<u32x4*>(out + unit * 8) = *reinterpret_cast<const u32x4*>(src);
+}
+
+// D = 768 (ViT-B) and 512 (test models): whole 64-column statistics slots per wave (D >= 512) plus at most half of a shared one, X (D / 64 x
+// 8 KiB) + two U buffers within the CU's 160 KiB of LDS, and a wave's share of the [64, D] f32 accumulator (D / 8 registers) within its
+// register file.  The hidden width walks in chunks of 128; weight pairs only on the f16 path.
 bool mlp_fused_supported(int M, int D, int Mlp, int f16, int split) {
     if (M <= 0 || (D != 768 && D != 512) || Mlp <= 0 || (Mlp % 128)) return false;
     if (split && !f16) return false;
     return true;
+}
+
+size_t mlp_fused_packed_bytes(int D, int Mlp, int split) {
+    return (size_t)2 * D * Mlp * 2 * (split ? 2 : 1);   // both matrices, every element once (hi and lo when split)
+}
+
+hipError_t launch_mlp_pack_weights(const bf16_t* W1, int ldw1, const bf16_t* W2, int ldw2, int D, int Mlp, int split, bf16_t* out, hipStream_t stream) {
+    if (!mlp_fused_supported(1, D, Mlp, split ? 1 : 0, split) || !W1 || !W2 || !out) return hipErrorInvalidValue;
+    const int sp = split ? 2 : 1;
+    if (ldw1 < sp * D || ldw2 < sp * Mlp || (ldw1 % 8) || (ldw2 % 8)) return hipErrorInvalidValue;
+    const int nchunks = Mlp / 128;
+    const long long units = (long long)mlp_fused_packed_bytes(D, Mlp, split) / 16;
+    const dim3 grid((unsigned)((units + 255) / 256));
+    if (D == 768) {
+        if (split) hipLaunchKernelGGL((ivit_mlp_pack_weights<12, 2>), grid, dim3(256), 0, stream, W1, ldw1, W2, ldw2, nchunks, out);
+        else hipLaunchKernelGGL((ivit_mlp_pack_weights<12, 1>), grid, dim3(256), 0, stream, W1, ldw1, W2, ldw2, nchunks, out);
+    } else {
+        if (split) hipLaunchKernelGGL((ivit_mlp_pack_weights<8, 2>), grid, dim3(256), 0, stream, W1, ldw1, W2, ldw2, nchunks, out);
+        else hipLaunchKernelGGL((ivit_mlp_pack_weights<8, 1>), grid, dim3(256), 0, stream, W1, ldw1, W2, ldw2, nchunks, out);
+    }
+    return hipGetLastError();
 }
 
 const char* mlp_fused_kernel_name(const MlpFusedParams& p) {
@@ -33,16 +74,13 @@ const char* mlp_fused_kernel_name(const MlpFusedParams& p) {
 
 hipError_t launch_mlp_fused(const MlpFusedParams& p, hipStream_t stream) {
     if (!mlp_fused_supported(p.M, p.D, p.Mlp, p.f16, p.split)) return hipErrorInvalidValue;
-    const int sp = p.split ? 2 : 1;
-    if (!p.X || !p.ln_part_in || !p.W1 || !p.c1 || !p.s1 || !p.W2 || !p.b2 || !p.resid || !p.out) return hipErrorInvalidValue;
+    if (!p.X || !p.ln_part_in || !p.Wp || !p.c1 || !p.s1 || !p.b2 || !p.resid || !p.out) return hipErrorInvalidValue;
     if (p.stats_out && (!p.xb || !p.ln_part_out || (p.ldxb % 8))) return hipErrorInvalidValue;
-    if ((p.ldx % 8) || (p.ldw1 % 8) || (p.ldw2 % 8) || (p.ldo % 4) || (p.ldr % 4)) return hipErrorInvalidValue;   // 16-byte rows for the DMA / the f32 quads
-    if (p.ldx < p.D || p.ldw1 < sp * p.D || p.ldw2 < sp * p.Mlp) return hipErrorInvalidValue;
-    if ((long long)p.ldw1 * 2 * 256 >= (1ll << 31) || (long long)p.ldw2 * 2 * 256 >= (1ll << 31)) return hipErrorInvalidValue;   // 32-bit lane offsets of the DMA sources
+    if ((p.ldx % 8) || (p.ldo % 4) || (p.ldr % 4) || p.ldx < p.D) return hipErrorInvalidValue;   // 16-byte rows for the DMA / the f32 quads
     void (*kernel)(MlpFusedParams) =
         p.D == 768 ? (p.split ? ivit_mlp_fused_f16x_d768 : p.f16 ? ivit_mlp_fused_f16_d768 : ivit_mlp_fused_bf16_d768)
                    : (p.split ? ivit_mlp_fused_f16x_d512 : p.f16 ? ivit_mlp_fused_f16_d512 : ivit_mlp_fused_bf16_d512);
-    const int lds = (p.D / 64) * 8192 + 4 * 16384;
+    const int lds = (p.D / 64) * 8192 + 2 * 16384;
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(ceil_div(p.M, 64)), dim3(512), lds, stream, p);

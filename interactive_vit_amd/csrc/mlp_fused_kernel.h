@@ -7,61 +7,88 @@
 //
 //     phase 1   acc1[64 x 128]  = X[64 x D] . W1'[chunk, D]^T          (K = D: ND = D / 64 K-tiles, X resident in LDS)
 //     epilogue  U[64 x 128]     = rn16(gelu(rstd (acc1 - mean s) + c))  -> LDS (16 KiB), read back as MFMA operand fragments (registers)
-//     phase 2   acc2[64 x D]   += U . W2[:, chunk]^T                    (K = 128; acc2 = 96 VGPRs per lane, live for the whole kernel)
+//     phase 2   acc2[64 x D]   += U . W2[:, chunk]^T                    (K = 128; acc2 = D / 8 VGPRs per lane, live for the whole kernel)
 //
-// and finishes with the residual epilogue of the MLP-down GEMM (gemm_epilogue_family<EK = 1 / 3>).  The MFMA sequence per accumulator is the
-// one the two GEMM kernels issue (K-tiles ascending, kk = 0, 1 inside; hi before lo for split weights), the epilogue arithmetic is theirs:
-// outputs are BIT-IDENTICAL to launch_gemm(EPI_LNFOLD_GELU_BF16) + launch_gemm(EPI_BIAS_RESID_STATS) (tools/mlp_fused_bench, tests).
+// and finishes with the residual epilogue of the MLP-down GEMM.  The MFMA sequence per accumulator is the one the two GEMM kernels issue
+// (K-tiles ascending, kk = 0, 1 inside; hi before lo for split weights), the epilogue arithmetic is theirs: outputs are BIT-IDENTICAL to
+// launch_gemm(EPI_LNFOLD_GELU_BF16) + launch_gemm(EPI_BIAS_RESID_STATS) (tools/mlp_fused_bench, tests/test_gpu_parity.py).
 //
 // What bounds it: weights.  Every workgroup streams all of W1' and W2 (9.4 MB at ViT-B/16) through its CU's vector-memory return path
-// (42-47 B/clk, profiles/r03b_operand_path_probe.txt): 393 KB per chunk against 6.1 k cycles of MFMA.  So the loop is a weight STREAM:
-//   * 16-KiB slots (W1': 128 hidden rows x 64 k; W2: 64 output columns x 128 hidden) in a ring of FOUR LDS buffers filled by LDS-DMA
-//     (global_load_lds_dwordx4, 2 pieces per wave and slot), issued three slots ahead behind a counted s_waitcnt vmcnt - 32-48 KiB in
-//     flight per CU at all times, no drain in the loop;
-//   * one s_barrier per slot ("step"); the fragments of slot u + 1 are read from LDS during the MFMAs of slot u (register double buffer), so
-//     a step is [wait + barrier, issue DMA of slot u + 4 into the buffer slot u just vacated, ds_read slot u + 1, 8 MFMAs per wave];
-//   * LDS = X (ND x 8 KiB) + 4 x 16 KiB = 160 KiB at D = 768: U has no home of its own - it is written into the buffer of the FIRST W2 slot
-//     once that slot's fragments are in registers (one extra barrier per chunk), and that buffer's next DMA is issued one step late.
-// Wave layout: 8 waves = 2 (rows) x 4; phase 1: wave (wr, wc) owns rows 32 wr.., hidden columns 32 wc.. of the chunk (2 x 2 fragments);
-// phase 2: rows 32 wr.., output columns {64 (wc + 4 g) + 16 j} - i.e. WHOLE 64-column statistics slots wc, wc + 4, wc + 8, one 16-column
-// fragment j of each per W2 slot (the W2 slot gathers those rows: an LDS-DMA source address is per lane) - so the residual / statistics
-// epilogue of a wave is exactly the (FM = 2, FN = 4) epilogue of the GEMM kernels, slot by slot.
+// (42-52 B/clk, profiles/r03b_operand_path_probe.txt): 393 KB per chunk against 6.1 k cycles of MFMA.  The first structure (weights through a
+// ring of LDS buffers, one barrier per 16-KiB slot: profiles/r05_fused_mlp_v1.txt) lost to the two launches - the LDS that X leaves holds too
+// little DMA in flight, and in barrier lockstep MFMA, LDS reads and DMA do not overlap.  This one shares NO weight fragment between waves:
+//   * 1 x 8 wave layout: wave w owns ALL 64 rows and, in phase 1, hidden columns 16 w .. of the chunk (4 x 1 fragments), in phase 2 the output
+//     columns of one whole 64-column statistics slot (w) plus half of a shared one (8 + w / 2) - D / 8 columns, (4 x ND / 2) fragments;
+//   * so an operand stream that nobody shares does not go through LDS at all (cdna_hip_programming.md, "GEMV / M <= 16" row): both matrices
+//     are re-laid ONCE (launch_mlp_pack_weights) into the order the kernel consumes them, 1-KiB blocks that ARE MFMA fragments (lane l holds
+//     row l & 15, k-chunk l >> 4), and every wave pulls its own contiguous stream with plain 16-byte-per-lane loads, R blocks (8 KiB) ahead in
+//     registers: 64 KiB in flight per CU, waits counted by hipcc itself (no LDS-DMA in the loop, so it can);
+//   * LDS holds X (ND x 8 KiB, read 8 x redundantly: 4 fragment reads per K-step) and two U buffers; ONE s_barrier per chunk (U written ->
+//     U read; the second buffer makes the write-after-read side free), so the waves of a CU drift apart and fill each other's stalls.
+// The residual / statistics epilogue: a wave's whole slot is the (FM = 4, FN = 4) epilogue of the GEMM kernels; the two halves of a shared slot
+// chain their row sums through LDS in the GEMM epilogue's own order (three barriers, once per kernel), so the pairs come out bit-identical too.
 #pragma once
 #include "gemm_kernel.h"
 #include <utility>
 
 namespace ivit {
 
-using MlpTile = GemmTile<2, 4, 2, 4>;   // shape constants for the shared epilogues: 2 x 4 waves of (2 x 4) fragments = 64 rows x 256 columns per "pass"
+using MlpTile = GemmTile<1, 8, 4, 4>;   // shape constants for the shared epilogues: one wave = 4 x 4 fragments = 64 rows x 64 columns
 
+#ifndef IVIT_MLPF_R
+#define IVIT_MLPF_R 8       // weight blocks (KiB) in flight per wave at D = 768
+#endif
+#ifndef IVIT_MLPF_XSETS
+#define IVIT_MLPF_XSETS 2   // register sets for the X fragments (2: the next K-tile's reads return under this K-tile's MFMAs)
+#endif
+#ifndef IVIT_MLPF_EPI_G
+#define IVIT_MLPF_EPI_G 4   // fragment rows whose residual loads are in flight together in the final epilogue (4 = the whole slot)
+#endif
 template <int ND_, int SPLIT_>
 struct MlpFusedGeom {
     static constexpr int ND = ND_, SPLIT = SPLIT_;
     static constexpr int BM = 64, HC = 128, THREADS = 512;
-    static constexpr int P = ND * SPLIT;          // phase-1 steps (W1' slots) per chunk
-    static constexpr int TS = 2 * P;              // steps per chunk
-    static constexpr int NG = ND / 4;             // 64-column statistics slots per wave
-    static constexpr int X_BYTES = ND * 8192, SLOT = 16384, LDS_BYTES = X_BYTES + 4 * SLOT;
-    static constexpr int UC = P - 5;              // step that loads the chunk's fold vectors (consumed after step P - 1)
-    static_assert(ND % 4 == 0 && P >= 8, "D must be a multiple of 256 and at least 512");
+    static constexpr int P = ND * SPLIT;            // phase-1 steps per chunk (one 64-deep K-tile of W1' each; split: hi / lo alternate)
+    static constexpr int NF = ND / 2;               // output column fragments per wave (D / 8 columns)
+    static constexpr int NH = NF - 4;               // ... of which the last NH belong to the shared slot (0 at D = 512, 2 at D = 768)
+    static constexpr int P2 = 2 * NF;               // phase-2 steps per chunk: two passes (hidden halves of 64) over the NF column fragments
+    static constexpr int NB1 = 2 * P, NB2 = 2 * SPLIT * P2; // 1-KiB fragment blocks per wave and chunk
+    static constexpr int CB = NB1 + NB2;            // = 48 (96 split) at D = 768
+    static constexpr int R = (ND == 12 ? IVIT_MLPF_R : 8);   // blocks in flight per wave (4 VGPRs each)
+    static constexpr int X_BYTES = ND * 8192, U_BYTES = 16384, LDS_BYTES = X_BYTES + 2 * U_BYTES;
+    static constexpr int UC = P - 3;                // phase-1 step that loads the chunk's fold vectors
+    static_assert(ND == 8 || ND == 12, "D = 512 or 768: whole statistics slots per wave plus at most half of a shared one");
+    static_assert(CB % R == 0, "the register ring wraps at the chunk boundary");
 };
 
-// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>) (a 48-step body is beyond what #pragma unroll accepts)
+// where block b of wave w's stream for chunk c comes from (host + device: the pack kernel and its tests)
+// phase 1 (b < NB1): K-tile s = b / 2 of W1' (split: K-tiles alternate hi / lo), 32-deep half kk = b % 2: rows c * 128 + 16 w + [0, 16)
+// phase 2: hidden half h (64 of the chunk's 128; split: hidden K-tile 2 c + h), column fragment t, q: unsplit k-step q of 32 hidden; split hi (q < 2) / lo, kk = q & 1
+template <int ND, int SPLIT>
+__host__ __device__ inline void mlpf_block_source(int c, int w, int b, int lane, bool* is_w1, int* row, int* col) {
+    using G = MlpFusedGeom<ND, SPLIT>;
+    const int r16 = lane & 15, kc = lane >> 4;
+    if (b < G::NB1) {
+        *is_w1 = true;
+        *row = c * 128 + 16 * w + r16;
+        *col = (b >> 1) * 64 + (b & 1) * 32 + 8 * kc;
+    } else {
+        const int b2 = b - G::NB1, h = b2 / (G::NF * 2 * SPLIT), rem = b2 % (G::NF * 2 * SPLIT), t = rem / (2 * SPLIT), q = rem % (2 * SPLIT);
+        *is_w1 = false;
+        *row = (t < 4 ? 64 * w + 16 * t : 64 * (8 + (w >> 1)) + 32 * (w & 1) + 16 * (t - 4)) + r16;
+        *col = SPLIT == 1 ? c * 128 + 64 * h + 32 * q + 8 * kc : (2 * c + h) * 128 + (q >> 1) * 64 + (q & 1) * 32 + 8 * kc;
+    }
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
 template <class F, int... I>
 __device__ __forceinline__ void mlpf_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void mlpf_static_for(F&& f) { mlpf_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 #ifndef IVIT_MLPF_TOUCH
-#define IVIT_MLPF_TOUCH 1   // 0 (A/B builds): no L2 warm-up loads
+#define IVIT_MLPF_TOUCH 1   // 0 (A/B builds): no L2 warm-up loads (one dword per lane and chunk of the NEXT chunk's stream)
 #endif
-#ifndef IVIT_MLPF_STAGGER
-#define IVIT_MLPF_STAGGER 1   // 0 (A/B builds): every wave runs the early-MFMA order
-#endif
-#ifndef IVIT_MLPF_ORDER
-#define IVIT_MLPF_ORDER 1   // 0 (A/B builds): leave the instruction order inside a step to hipcc
-#endif
-#define IVIT_MLPF_WAIT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (((N) >> 4) << 14))   /* vmcnt(N) lgkmcnt(0), gfx9 encoding: a builtin, so hipcc's own wait bookkeeping sees it */
 
 #ifdef IVIT_MLPF_STAMPS   // tools/mlp_fused_bench only
 #define IVIT_MLPF_STAMP(slot)                                                                                  \
@@ -76,287 +103,308 @@ __device__ __forceinline__ void mlpf_static_for(F&& f) { mlpf_static_for_impl(f,
 #define IVIT_MLPF_STAMP(slot) do { } while (0)
 #endif
 
-// DBG (tools/mlp_fused_bench only; 0 in the product): timing ablations, a bit mask - 1 = no DMA inside the loop, 2 = no MFMA, 4 = no LDS fragment reads,
-// 8 = no s_barrier inside the loop (results are wrong in every ablation; only the time is read)
+// DBG (tools/mlp_fused_bench only; 0 in the product): timing ablations, a bit mask - 1 = no weight loads inside the loop, 2 = no MFMA,
+// 4 = no LDS fragment reads (results are wrong in every ablation; only the time is read)
 template <int ND, int SPLIT, class OP, int DBG = 0>
 __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* smem) {
     using G = MlpFusedGeom<ND, SPLIT>;
     using T = MlpTile;
-    constexpr int P = G::P, TS = G::TS, NG = G::NG, SLOT = G::SLOT, UC = G::UC;
+    constexpr int P = G::P, P2 = G::P2, NB1 = G::NB1, CB = G::CB, R = G::R, NH = G::NH, UC = G::UC;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int m0 = blockIdx.x * G::BM;
-    char* ring = smem + G::X_BYTES;
+    char* ubuf = smem + G::X_BYTES;
     IVIT_MLPF_STAMP(0);
 
-    // ---- LDS-DMA sources: 8 rows x 128 B per wave-instruction, the 16-B chunk XOR-swizzled with the row on the SOURCE side.  A source address is
-    //      (wave-uniform base of the slot) + (32-bit lane offset): the uniform part is scalar arithmetic, the lane part one register per matrix
-    const int r_in = lane >> 3, swz = (lane & 7) ^ r_in;
-    const size_t ldw1_b = (size_t)p.ldw1 * 2, ldw2_b = (size_t)p.ldw2 * 2;
-    const unsigned w1_off = (unsigned)((wave * 8 + r_in) * (int)ldw1_b + swz * 16);
-    // W2 slot t gathers, for every wave column q, the 16 output columns 64 (q + 4 (t >> 2)) + 16 (t & 3) ..: piece `wave` = (q = wave >> 1, half = wave & 1)
-    const unsigned w2_off = (unsigned)((64 * (wave >> 1) + 8 * (wave & 1) + r_in) * (int)ldw2_b + swz * 16);
-    auto glds = [](const char* src, char* dst) {
-        __builtin_amdgcn_global_load_lds((const IVIT_GLOBAL void*)src, (IVIT_LDS void*)dst, 16, 0, 0);
+    // ---- the weight stream of this wave: block b of chunk cc at Wp + ((cc * 8 + wave) * CB + b) KiB, lane l its 16 bytes at l * 16
+    const char* wp = reinterpret_cast<const char*>(p.Wp) + (size_t)wave * CB * 1024;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto ldw = [&](int cc, int b) -> bf16x8 {   // b: compile-time constant wherever this is called
+        const char* sb = wp + (size_t)cc * (8 * CB * 1024) + b * 1024;
+        return *reinterpret_cast<const bf16x8*>(sb + lane16);
     };
-    // slot s of chunk cc into ring buffer s & 3 (2 pieces per wave; s is a compile-time constant wherever this is called)
-    auto dma_slot = [&](int cc, int s) {
-        char* dst = ring + (s & 3) * SLOT + wave * 1024;
-        if (s < P) {            // W1': hidden rows cc * 128 + [0, 128), K-tile s (split: hi / lo K-tiles alternate)
-            const char* sb = reinterpret_cast<const char*>(p.W1) + (size_t)cc * 128 * ldw1_b + s * 128;
-            glds(sb + w1_off, dst);
-            glds(sb + 64 * ldw1_b + w1_off, dst + 8192);
-        } else {                // W2: 64 gathered output rows x hidden [cc * 128, +128) as two 64-deep K-tile images (split: [hi | lo] of 64 hidden)
-            const int v = s - P, t = v / SPLIT, sub = v % SPLIT;
-            const char* sb = reinterpret_cast<const char*>(p.W2) + (size_t)(256 * (t >> 2) + 16 * (t & 3)) * ldw2_b + (size_t)(cc * SPLIT + sub) * 256;
-            glds(sb + w2_off, dst);
-            glds(sb + 128 + w2_off, dst + 8192);
-        }
-    };
-
-    // ---- L2 warm-up one chunk ahead.  The workgroups that share an XCD (observed: blockIdx mod 8; speed only) ask for the same weight lines at almost
-    //      the same time, so every one of them waits out the L2 miss of the first (Infinity Cache: ~0.6 us under this load - with 32-48 KiB in flight
-    //      per CU that, not the CU's 45 B/clk return path, set the rate: profiles/r05_fused_mlp.txt).  Once per chunk every lane loads ONE dword of the
-    //      next chunk's weight block (its 128-byte lines dealt over the workgroups of the XCD group, 2 x 256 per workgroup), fifteen steps before the
-    //      first DMA that needs them: the DMA then hits L2.
-    constexpr int W1_LPR = SPLIT * ND, W1_LINES = 128 * W1_LPR, W2_LPR = 2 * SPLIT, W2_LINES = ND * 64 * W2_LPR;   // lines per row / per chunk block
-    static_assert(W1_LINES == W2_LINES, "the two halves of the workgroup warm equal shares");
-    // waves 0-3 take W1' lines, waves 4-7 W2 lines (a wave-uniform choice: the base stays scalar, the lane part is one 32-bit offset)
-    const int touch_line = ((int)(blockIdx.x >> 3) * 256 + (int)(threadIdx.x & 255)) % W1_LINES;
-    const unsigned touch_off = wave < 4 ? (unsigned)((touch_line / W1_LPR) * (int)ldw1_b + (touch_line % W1_LPR) * 128)
-                                        : (unsigned)((touch_line / W2_LPR) * (int)ldw2_b + (touch_line % W2_LPR) * 128);
-    auto touch_ptr = [&](int cc) -> const unsigned* {
-        const char* sb = wave < 4 ? reinterpret_cast<const char*>(p.W1) + (size_t)cc * 128 * ldw1_b : reinterpret_cast<const char*>(p.W2) + (size_t)cc * SPLIT * 256;
-        return reinterpret_cast<const unsigned*>(sb + touch_off);
-    };
+    bf16x8 wq[R];   // the register ring: block b lives in wq[b % R]
+#pragma unroll
+    for (int b = 0; b < R; ++b) wq[b] = ldw(0, b);
+    // this lane's line of a chunk's 8 CB KiB for the L2 warm-up loads (see the phase-1 epilogue)
+    const char* touch_base = reinterpret_cast<const char*>(p.Wp) + (size_t)((((int)blockIdx.x >> 3) * 512 + (int)threadIdx.x) % (64 * CB)) * 128;
     unsigned touch = 0;
+    if (IVIT_MLPF_TOUCH && p.Mlp > G::HC) touch = *reinterpret_cast<const unsigned*>(touch_base + (size_t)(8 * CB * 1024));   // chunk 1 (chunk 0 is being loaded)
 
-    // ---- prologue: X rows (ND K-tile images of 64 rows x 128 B) and the first four slots
+    // ---- X rows -> LDS by LDS-DMA (ND K-tile images of 64 rows x 128 B, 16-B chunk XOR-swizzled with the row on the source side)
     {
+        const int r_in = lane >> 3, swz = (lane & 7) ^ r_in;
         const char* x_lane = reinterpret_cast<const char*>(p.X) + (size_t)(m0 + wave * 8 + r_in) * ((size_t)p.ldx * 2) + swz * 16;
 #pragma unroll
-        for (int kt = 0; kt < ND; ++kt) glds(x_lane + kt * 128, smem + kt * 8192 + wave * 1024);
+        for (int kt = 0; kt < ND; ++kt)
+            __builtin_amdgcn_global_load_lds((const IVIT_GLOBAL void*)(x_lane + kt * 128), (IVIT_LDS void*)(smem + kt * 8192 + wave * 1024), 16, 0, 0);
     }
+    // (mean, rstd) of the 64 rows from the statistics pairs (the fold every _lf GEMM does): one thread per row into the second U buffer, then every
+    // lane takes the four rows of its accumulator fragments.  Rows past M: a valid row's statistics (their outputs are never stored).
+    float mean_i[4], rstd_i[4];
+    {
+        float2* st = reinterpret_cast<float2*>(ubuf + G::U_BYTES);
+        if (threadIdx.x < 64) st[threadIdx.x] = ln_row_stats_from_pairs(p.ln_part_in, min(m0 + (int)threadIdx.x, p.M - 1), ND * 64, p.ln_eps);
+        // X has landed (every wave drains its own pieces), the statistics are written.  A builtin, not inline asm: hipcc's own wait bookkeeping must
+        // see that the LDS-DMA is retired, or it drains the weight stream at every chunk for fear of it (cdna_hip_programming.md, 3 .s-level traps (b))
+        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int s = 0; s < 4; ++s) dma_slot(0, s);
-
-    // (mean, rstd) of this lane's two accumulator rows, from the statistics pairs (the fold every _lf GEMM does); rows past M: a valid row's
-    float mean_i[2], rstd_i[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float2 st = ln_row_stats_from_pairs(p.ln_part_in, min(m0 + 32 * wr + 16 * i + fr, p.M - 1), ND * 64, p.ln_eps);
-        mean_i[i] = st.x;
-        rstd_i[i] = st.y;
+        for (int i = 0; i < 4; ++i) { const float2 v = st[16 * i + fr]; mean_i[i] = v.x; rstd_i[i] = v.y; }
     }
 
-    // ---- LDS read offsets (row r, 16-B chunk q) -> r * 128 + ((q ^ (r & 7)) << 4); kk = 1 flips bit 2 of the chunk
+    // ---- LDS read offsets (row r, 16-B chunk q) -> r * 128 + ((q ^ (r & 7)) << 4); kk = 1 flips bit 2 of the chunk; fragment row i adds 2048
     const int a0 = (fq ^ (fr & 7)) << 4;
-    const int off_w1[2] = {(32 * wc + fr) * 128 + a0, (32 * wc + fr) * 128 + (a0 ^ 64)};
-    const int off_x[2] = {(32 * wr + fr) * 128 + a0, (32 * wr + fr) * 128 + (a0 ^ 64)};
-    const int off_w2[2] = {(16 * wc + fr) * 128 + a0, (16 * wc + fr) * 128 + (a0 ^ 64)};
+    const int off_x[2] = {fr * 128 + a0, fr * 128 + (a0 ^ 64)};
     auto ld16 = [](const char* q) { return *reinterpret_cast<const bf16x8*>(q); };
 
-    f32x4 acc2[NG][2][4];
+    constexpr int NHA = NH > 0 ? NH : 1;
+    f32x4 accF[4][4];     // the wave's own statistics slot: rows 16 i + fr, columns 64 w + 16 j + 4 fq ..
+    f32x4 accH[4][NHA];   // its half of the shared slot 8 + w / 2: columns 64 (8 + w / 2) + 32 (w & 1) + 16 j + 4 fq ..
+    f32x4 acc1[4];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) accF[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc2[g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 acc1[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 wf[2][2][2] = {};    // W1' fragments [set][j][kk]: set = slot & 1
-    bf16x8 xf[2][2][2] = {};    // X fragments [set][i][kk]: set = K-tile & 1 (split: kept across the hi / lo pair)
-    bf16x8 w2f[2][4] = {};      // W2 fragments [set][k-step]
-    bf16x8 uf[2][4] = {};       // U fragments [i][k-step of 32 hidden]
-    float4 c4[2], s4[2];   // fold vectors of the chunk's hidden columns 32 wc + 16 j + 4 fq ..
-
-    auto read_w1 = [&](int s, bf16x8 (&f)[2][2]) {
-        const char* b = ring + (s & 3) * SLOT;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) f[j][kk] = ld16(b + off_w1[kk] + j * 2048);
-    };
-    auto read_x = [&](int kt, bf16x8 (&f)[2][2]) {
+        for (int j = 0; j < NHA; ++j) accH[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 xf[IVIT_MLPF_XSETS][4][2] = {};   // X fragments [set = K-tile mod sets][i][kk]
+    bf16x8 uf[4][2] = {};      // U fragments of the current hidden half [i][k-step of 32 hidden]
+    float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = c4;   // fold vectors of the chunk's hidden columns 16 w + 4 fq ..
+    auto read_x = [&](int kt, bf16x8 (&f)[4][2]) {
+        if (DBG & 4) return;
         const char* b = smem + kt * 8192;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) f[i][kk] = ld16(b + off_x[kk] + i * 2048);
+            for (int i = 0; i < 4; ++i) f[i][kk] = ld16(b + off_x[kk] + i * 2048);
     };
-    auto read_w2 = [&](int s, bf16x8 (&f)[4]) {
-        const char* b = ring + (s & 3) * SLOT;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f[q] = ld16(b + (q >> 1) * 8192 + off_w2[q & 1]);
-    };
-
-    // everything issued so far has landed (hipcc waits vmcnt(0) for the statistics loads above anyway); publish, then slot 0's fragments
-    IVIT_MLPF_WAIT(0);
-    __builtin_amdgcn_s_barrier();
-    read_w1(0, wf[0]);
     read_x(0, xf[0]);
     IVIT_MLPF_STAMP(1);
 
     const int nchunks = p.Mlp / G::HC;
-    // The chunk loop in two instruction orders (LATE = waves 4-7, which share their SIMDs with waves 0-3): the early half of the workgroup starts a
-    // step with its MFMAs and issues its LDS reads / DMA between them, the late half issues its memory instructions first and its MFMAs after
-    // them - on every SIMD one wave is in its matrix burst while its partner is in its memory burst, inside the same barrier interval.
-    auto chunk_loop = [&](auto late_tag) {
-    constexpr bool LATE = decltype(late_tag)::value;
     for (int c = 0; c < nchunks; ++c) {
-        const int cn = c + 1 < nchunks ? c + 1 : 0;   // the last chunk's look-ahead re-loads chunk 0 into dead buffers: every count stays constant
-        mlpf_static_for<TS>([&](auto u_tag) {
-            constexpr int u = decltype(u_tag)::value;   // compile-time step index: every buffer, register set and wait count below is a constant
-            // ---- slot u + 1 has landed for this wave: all but the N youngest vector-memory operations are done (2 per slot in flight behind it; the
-            //      fold vectors add 4 for two steps; one slot fewer is in flight at step P + 1, see below); LDS reads of the previous step retired
-            //      too, so after the barrier the buffer of slot u may be overwritten
-            if (u == P + 1) IVIT_MLPF_WAIT(2);
-            else if (u == UC + 1 || u == UC + 2) { if (IVIT_MLPF_TOUCH) IVIT_MLPF_WAIT(9); else IVIT_MLPF_WAIT(8); }
-            else IVIT_MLPF_WAIT(4);
-            if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (u == UC) {   // fold vectors of this chunk, ordinary loads issued BEFORE this step's DMA (they are older than slot u + 4: retired by the wait of step u + 3)
+        const int cn = c + 1 < nchunks ? c + 1 : 0;   // the last chunk's look-ahead re-loads chunk 0: valid memory, never used
+        // ---------------- phase 1: acc1 = X . W1'[chunk]^T, one K-tile per step (split: hi, then lo against the same X fragments)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    c4[j] = *reinterpret_cast<const float4*>(p.c1 + c * 128 + 32 * wc + 16 * j + 4 * fq);
-                    s4[j] = *reinterpret_cast<const float4*>(p.s1 + c * 128 + 32 * wc + 16 * j + 4 * fq);
-                }
-                if (IVIT_MLPF_TOUCH) touch = *touch_ptr(cn);   // the NEXT chunk's weights into this XCD's L2 (see touch_ptr)
+        for (int i = 0; i < 4; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // (zeroed here, not after its epilogue: dead, not live, through phase 2)
+        mlpf_static_for<P>([&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value, kt = s / SPLIT;
+            if constexpr (IVIT_MLPF_XSETS == 2 && s + 1 < P && (s + 1) % SPLIT == 0) read_x(kt + 1, xf[(kt + 1) & 1]);   // the next K-tile's fragments return under this step's MFMAs
+            if constexpr (s == UC) {
+                c4 = *reinterpret_cast<const float4*>(p.c1 + c * 128 + 16 * wave + 4 * fq);
+                s4 = *reinterpret_cast<const float4*>(p.s1 + c * 128 + 16 * wave + 4 * fq);
             }
-            if (u == UC + 3 && IVIT_MLPF_TOUCH) asm volatile("" ::"v"(touch));   // retired by this step's wait; the value is never used
-            // ---- DMA: slot u + 4 into the buffer slot u vacated (its fragments were read during step u - 1).  The buffer of slot P holds U during
-            //      step P, so its refill (slot P + 4) waits one step and goes out together with slot P + 5.
-            if (u != P && !(DBG & 1)) {
-                if (u == P + 1) { dma_slot(c, P + 4); dma_slot(c, P + 5); }
-                else if (u + 4 < TS) dma_slot(c, u + 4);
-                else dma_slot(cn, u + 4 - TS);
-            }
-            if (u == P) {   // U (written after the extra barrier below, published by this step's barrier) -> operand fragments
-                const char* b = ring + (P & 3) * SLOT;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) uf[i][q] = ld16(b + (q >> 1) * 8192 + off_x[q & 1] + i * 2048);
-            }
-            // ---- fragments of slot u + 1 (they return under this step's MFMAs)
-            if constexpr ((DBG & 4) != 0) {
-            } else if constexpr (u + 1 < P) {
-                read_w1(u + 1, wf[(u + 1) & 1]);
-                if ((u + 1) % SPLIT == 0) read_x((u + 1) / SPLIT, xf[((u + 1) / SPLIT) & 1]);
-            } else if constexpr (u + 1 < TS) {
-                read_w2(u + 1, w2f[(u + 1 - P) & 1]);
-            } else {
-                read_w1(0, wf[0]);
-                read_x(0, xf[0]);
-            }
-            // ---- MFMAs of slot u
-            if constexpr ((DBG & 2) != 0) {   // keep the fragments alive (cdna_hip_programming.md rule 17)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) { asm volatile("" ::"v"(wf[a][b][kk])); asm volatile("" ::"v"(xf[a][b][kk])); }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { asm volatile("" ::"v"(w2f[a][q])); asm volatile("" ::"v"(uf[a][q])); }
-            } else if constexpr (u < P) {
-                const int kt = u / SPLIT;
+            if constexpr (!(DBG & 2)) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc1[i][j] = OP::mfma(wf[u & 1][j][kk], xf[kt & 1][i][kk], acc1[i][j]);
+                    for (int i = 0; i < 4; ++i) acc1[i] = OP::mfma(wq[(2 * s + kk) % R], xf[kt % IVIT_MLPF_XSETS][i][kk], acc1[i]);
             } else {
-                const int v = u - P, t = v / SPLIT, sub = v % SPLIT;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int kk = 0; kk < 2; ++kk) {
+                    asm volatile("" ::"v"(wq[(2 * s + kk) % R]));
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        // unsplit: the slot's four k-steps of 32 hidden; split: hi (kk 0, 1) then lo (kk 0, 1) of hidden K-tile 2 c + sub
-                        const int ks = SPLIT == 1 ? q : 2 * sub + (q & 1);
-                        acc2[t >> 2][i][t & 3] = OP::mfma(w2f[v & 1][q], uf[i][ks], acc2[t >> 2][i][t & 3]);
-                    }
+                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(xf[kt % IVIT_MLPF_XSETS][i][kk]));
+                }
             }
-            // ---- issue order inside the step (one scheduling region): the MFMAs start at once - their fragments are in registers - and the next slot's
-            //      LDS reads (two per gap), then the DMA issues (one per gap), go out between them.  Left to itself hipcc puts the DMA issues first: every
-            //      wave of the workgroup is in the same step, so the matrix pipes then idle through them after each barrier.
-            if constexpr (DBG == 0 && u != P && IVIT_MLPF_ORDER) {
-                constexpr int NR = (u + 1 < P) ? (((u + 1) % SPLIT == 0) ? 8 : 4) : (u + 1 < TS ? 4 : 8);
-                constexpr int NV = (u == P + 1) ? 4 : 2;
-                if constexpr (LATE) {   // DMA issues first (the partner wave's MFMAs run beside them), then reads and MFMAs interleaved
-                    __builtin_amdgcn_sched_group_barrier(0x10, NV, 0);
+            if constexpr (!(DBG & 1)) {   // refill the two register slots just consumed: blocks R ahead in the stream.  (Issuing the refill of the PREVIOUS
+                                          // step's slots first in the step instead, ahead of this step's wait, measured 6 % slower: profiles/r05_fused_mlp.txt)
 #pragma unroll
-                    for (int k = 0; k < NR / 2; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); }
-                    __builtin_amdgcn_sched_group_barrier(0x8, 8 - NR / 2, 0);
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                for (int kk = 0; kk < 2; ++kk) wq[(2 * s + kk) % R] = ldw(c, 2 * s + kk + R);   // < CB: phase 2 follows in the same chunk
+            }
+            if constexpr (IVIT_MLPF_XSETS == 1 && s + 1 < P && (s + 1) % SPLIT == 0) read_x(kt + 1, xf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---------------- phase-1 epilogue (gemm_epilogue_lnfold's arithmetic): u = rn16(gelu(rstd (acc - mean s) + c)), 4 consecutive hidden per lane
+        {
+            // L2 warm-up one chunk ahead.  In a forward every layer's 9.4 MB of weights are cold (twelve layers of them do not stay in L2), and the workgroups that
+            // share an XCD (observed: blockIdx mod 8; speed only) ask for the same lines at almost the same time: all of them wait out the miss of the first.
+            // One dword per lane of the NEXT chunk's block (its 128-byte lines dealt over the workgroups of the XCD group) starts those misses half a chunk
+            // early.  Placed HERE because vector-memory results return in order: a load that misses to HBM holds up the wave's wait for every younger load,
+            // and behind this point come ~0.6 us of GELU arithmetic and four steps on operands that are already in flight.
+            if (IVIT_MLPF_TOUCH) touch = *reinterpret_cast<const unsigned*>(touch_base + (size_t)cn * (8 * CB * 1024));
+            char* ub = ubuf + (c & 1) * G::U_BYTES + (wave >> 2) * 8192 + (fq & 1) * 8;
+            const int ch = 2 * (wave & 3) + (fq >> 1);
 #pragma unroll
-                    for (int k = 0; k < NR / 2; ++k) { __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); }
+            for (int i = 0; i < 4; ++i) {
+                const float mu = mean_i[i], rs = rstd_i[i];
+                float a[4] = {fmaf(rs, fmaf(-mu, s4.x, acc1[i][0]), c4.x), fmaf(rs, fmaf(-mu, s4.y, acc1[i][1]), c4.y),
+                              fmaf(rs, fmaf(-mu, s4.z, acc1[i][2]), c4.z), fmaf(rs, fmaf(-mu, s4.w, acc1[i][3]), c4.w)};
 #pragma unroll
-                    for (int k = 0; k < NV; ++k) { __builtin_amdgcn_sched_group_barrier(0x10, 1, 0); if (1 + NR / 2 + k < 8) __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); }
-                    if constexpr (1 + NR / 2 + NV < 8) __builtin_amdgcn_sched_group_barrier(0x8, 8 - (1 + NR / 2 + NV), 0);
+                for (int r = 0; r < 4; ++r) a[r] = gelu_erf(a[r]);
+                const int row = 16 * i + fr;
+                u32x2 pk = {OP::pack2(a[0], a[1]), OP::pack2(a[2], a[3])};
+                *reinterpret_cast<u32x2*>(ub + row * 128 + ((ch ^ (row & 7)) << 4)) = pk;
+            }
+        }
+        // U written by every wave -> published.  (The other U buffer was last read two chunks ago, before every wave's previous barrier: no second barrier.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- phase 2: acc2[:, fragment t] += U[:, half h] . W2[fragment t rows, half h of the chunk]^T, h = 0, 1 (k ascending per accumulator)
+        auto read_u = [&](int h) {
+            if (DBG & 4) return;
+            const char* b = ubuf + (c & 1) * G::U_BYTES + h * 8192;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) uf[i][kk] = ld16(b + off_x[kk] + i * 2048);
+        };
+        read_u(0);
+        mlpf_static_for<P2>([&](auto v_tag) {
+            constexpr int v = decltype(v_tag)::value, t = v % G::NF, NQ = 2 * SPLIT, b0 = NB1 + NQ * v;
+            if constexpr (v == G::NF) read_u(1);
+            if constexpr (v == P2 - 1) {
+                read_x(0, xf[0]);   // the next chunk's first K-tile
+                if (IVIT_MLPF_TOUCH) asm volatile("" ::"v"(touch));   // (the value is never used; the load is long complete)
+            }
+            if constexpr (!(DBG & 2)) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // unsplit: the two k-steps of 32 hidden; split: hi (kk 0, 1) then lo (kk 0, 1) of the hidden K-tile
+                        if constexpr (t < 4) accF[i][t] = OP::mfma(wq[(b0 + q) % R], uf[i][q & 1], accF[i][t]);
+                        else accH[i][t - 4] = OP::mfma(wq[(b0 + q) % R], uf[i][q & 1], accH[i][t - 4]);
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(wq[(b0 + q) % R]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) asm volatile("" ::"v"(uf[i][kk]));
+            }
+            if constexpr (!(DBG & 1)) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (b0 + q + R < CB) wq[(b0 + q) % R] = ldw(c, b0 + q + R);
+                    else wq[(b0 + q) % R] = ldw(cn, b0 + q + R - CB);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (u == P - 1) {
-                // ---- phase-1 epilogue (gemm_epilogue_lnfold's arithmetic): u = rn16(gelu(rstd (acc - mean s) + c)), 8 consecutive hidden per lane after the
-                //      fragment-pair lane swap, one 16-byte LDS store per fragment row
-                u32x4 pk[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float mu = mean_i[i], rs = rstd_i[i];
-                    float a[4] = {fmaf(rs, fmaf(-mu, s4[0].x, acc1[i][0][0]), c4[0].x), fmaf(rs, fmaf(-mu, s4[0].y, acc1[i][0][1]), c4[0].y),
-                                  fmaf(rs, fmaf(-mu, s4[0].z, acc1[i][0][2]), c4[0].z), fmaf(rs, fmaf(-mu, s4[0].w, acc1[i][0][3]), c4[0].w)};
-                    float b[4] = {fmaf(rs, fmaf(-mu, s4[1].x, acc1[i][1][0]), c4[1].x), fmaf(rs, fmaf(-mu, s4[1].y, acc1[i][1][1]), c4[1].y),
-                                  fmaf(rs, fmaf(-mu, s4[1].z, acc1[i][1][2]), c4[1].z), fmaf(rs, fmaf(-mu, s4[1].w, acc1[i][1][3]), c4[1].w)};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { a[r] = gelu_erf(a[r]); b[r] = gelu_erf(b[r]); }
-                    const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(a[0], a[1]), OP::pack2(b[0], b[1]), false, false);
-                    const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(a[2], a[3]), OP::pack2(b[2], b[3]), false, false);
-                    pk[i] = u32x4{lo[0], hi[0], lo[1], hi[1]};
-                    acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                // every wave holds slot P's fragments (read above, retired by this wait): its buffer becomes U
-                IVIT_MLPF_WAIT(6);   // lgkmcnt(0); the three slots in flight stay in flight
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                const int hcol = 32 * wc + (fq & 1) * 16 + (fq & ~1) * 4;   // first of this lane's 8 consecutive hidden columns
-                char* ub = ring + (P & 3) * SLOT + (hcol >> 6) * 8192;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = 32 * wr + 16 * i + fr;
-                    *reinterpret_cast<u32x4*>(ub + row * 128 + ((((hcol & 63) >> 3) ^ (row & 7)) << 4)) = pk[i];
-                }
-            }
         });
     }
-    };
-    if (IVIT_MLPF_STAGGER && wave >= 4) chunk_loop(std::true_type{});
-    else chunk_loop(std::false_type{});
     IVIT_MLPF_STAMP(2);
-    IVIT_MLPF_WAIT(0);   // the last chunk's look-ahead DMA still writes LDS
+#pragma unroll
+    for (int b = 0; b < R; ++b) asm volatile("" ::"v"(wq[b]));   // the look-ahead past the last chunk is waited for, not dropped mid-flight
 
-    // ---- residual epilogue of the MLP-down GEMM, one 64-column statistics slot at a time
+    // ---------------- residual epilogue of the MLP-down GEMM
     GemmParams gp{};
     gp.M = p.M; gp.N = p.D; gp.bias = p.b2; gp.resid = p.resid; gp.ldr = p.ldr; gp.out = p.out; gp.ldo = p.ldo;
     gp.xb = p.xb; gp.ldxb = p.ldxb; gp.ln_part = p.ln_part_out;
     gp.epi = p.stats_out ? EPI_BIAS_RESID_STATS : EPI_BIAS_RESID_F32;
+    // residual rows of the shared half slot first: they are in flight under the whole-slot epilogue below (the epilogue is a burst of dependent
+    // memory round trips on a CU with nothing else resident: everything that can be requested at once is)
+    constexpr int NHL = NH > 0 ? 2 : 1;
+    const int hslot = 8 + (wave >> 1), odd = wave & 1, n0 = 64 * hslot + 32 * odd;
+    float4 xh[4][NHL], bias_h[NHL];
+    bool row_ok[4];
+    if constexpr (NH > 0) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int n_base = 64 * (wc + 4 * g), m_base = m0 + 32 * wr;
-        if (p.stats_out) gemm_epilogue_family<T, 1, OP, 1>(gp, acc2[g], m_base, n_base, fr, fq);
-        else gemm_epilogue_family<T, 3, OP, 1>(gp, acc2[g], m_base, n_base, fr, fq);
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 16 * i + fr;
+            row_ok[i] = m < p.M;
+            const float* rs = p.resid + (size_t)(row_ok[i] ? m : p.M - 1) * p.ldr + n0 + 4 * fq;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xh[i][j] = *reinterpret_cast<const float4*>(rs + 16 * j);
+        }
+    }
+    // the wave's own slot: exactly the (FM = 4, FN = 4) epilogue of the GEMM kernels
+    if (p.stats_out) gemm_epilogue_family<T, 1, OP, IVIT_MLPF_EPI_G>(gp, accF, m0, 64 * wave, fr, fq);
+    else gemm_epilogue_family<T, 3, OP, IVIT_MLPF_EPI_G>(gp, accF, m0, 64 * wave, fr, fq);
+    if constexpr (NH > 0) {
+        // the shared slot 8 + w / 2: the even wave holds its fragments j = 0, 1, the odd wave j = 2, 3.  Same element arithmetic; the slot's row sum and
+        // M2 are the GEMM epilogue's sequential lane sums (j, then r), so the two waves CHAIN them through LDS: even -> odd (sum), odd -> even (slot
+        // mean), even -> odd (M2), a barrier each.  The scratch is the U buffer the last chunk did not use.
+        static_assert(NH == 0 || NH == 2, "half of a four-fragment slot");
+        float* xch = reinterpret_cast<float*>(ubuf + (nchunks & 1) * G::U_BYTES) + (wave >> 1) * 1024;   // three arrays of [4 i][64 lanes] per wave pair
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bias_h[j] = *reinterpret_cast<const float4*>(p.b2 + n0 + 16 * j + 4 * fq);
+        float sum[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mr = row_ok[i] ? m0 + 16 * i + fr : p.M - 1;
+            sum[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float v[4] = {xh[i][j].x + (accH[i][j][0] + bias_h[j].x), xh[i][j].y + (accH[i][j][1] + bias_h[j].y),
+                                    xh[i][j].z + (accH[i][j][2] + bias_h[j].z), xh[i][j].w + (accH[i][j][3] + bias_h[j].w)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accH[i][j][r] = v[r];
+                if (row_ok[i]) *reinterpret_cast<float4*>(p.out + (size_t)mr * p.ldo + n0 + 16 * j + 4 * fq) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (p.stats_out) {   // 16-bit copy: 16-byte stores through the fragment-pair lane swap, as the GEMM epilogue (the swap itself in every lane)
+                const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][0], accH[i][0][1]), OP::pack2(accH[i][1][0], accH[i][1][1]), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][2], accH[i][0][3]), OP::pack2(accH[i][1][2], accH[i][1][3]), false, false);
+                u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
+                if (row_ok[i]) *reinterpret_cast<u32x4*>(p.xb + (size_t)mr * p.ldxb + n0 + (fq & 1) * 16 + (fq & ~1) * 4) = pk;
+            }
+        }
+        if (p.stats_out) {   // (uniform branch: every wave takes the same barriers)
+            // 1. sequential lane sum: even wave starts from 0 over its 8 values, odd wave continues from the even wave's partial
+            if (!odd) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum[i] += accH[i][j][r];
+                    xch[i * 64 + lane] = sum[i];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            float lmean[4] = {0.f, 0.f, 0.f, 0.f};
+            if (odd) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float s_ = xch[i * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s_ += accH[i][j][r];
+                    s_ += __shfl_xor(s_, 16, 64);
+                    s_ += __shfl_xor(s_, 32, 64);
+                    sum[i] = s_;
+                    lmean[i] = s_ / 64.0f;
+                    xch[256 + i * 64 + lane] = lmean[i];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!odd) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lm = xch[256 + i * 64 + lane];
+                    float q2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float d = accH[i][j][r] - lm; q2 = fmaf(d, d, q2); }
+                    xch[512 + i * 64 + lane] = q2;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (odd) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float q2 = xch[512 + i * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float d = accH[i][j][r] - lmean[i]; q2 = fmaf(d, d, q2); }
+                    q2 += __shfl_xor(q2, 16, 64);
+                    q2 += __shfl_xor(q2, 32, 64);
+                    if (fq == 0 && row_ok[i]) p.ln_part_out[(size_t)(m0 + 16 * i + fr) * GEMM_LN_SLOTS + hslot] = make_float2(sum[i], q2);
+                }
+            }
+        }
     }
     IVIT_MLPF_STAMP(3);
 }

@@ -68,6 +68,9 @@ int main(int argc, char** argv) {
         CK(launch_fold_ln_weights(dw1u, D, Mlp, D, dg, dbeta, db1, dw1, ds1, dc1, 0, f16));
         CK(launch_f32_to_bf16(dw2f, Mlp, dw2, Mlp, D, Mlp, 0, f16));
     }
+    bf16_t* dwp;   // both matrices in the fused kernel's stream order
+    CK(hipMalloc(&dwp, mlp_fused_packed_bytes(D, Mlp, split)));
+    CK(launch_mlp_pack_weights(dw1, ldw1, dw2, ldw2, D, Mlp, split, dwp, 0));
     CK(hipDeviceSynchronize());
 
     // outputs: reference pair of launches vs the fused kernel
@@ -89,7 +92,7 @@ int main(int argc, char** argv) {
     };
     auto run_fused = [&](int stats, hipStream_t st) {
         MlpFusedParams p{};
-        p.X = dxb; p.ldx = D; p.ln_part_in = dpart; p.ln_eps = 1e-6f; p.W1 = dw1; p.ldw1 = ldw1; p.c1 = dc1; p.s1 = ds1; p.W2 = dw2; p.ldw2 = ldw2; p.b2 = db2;
+        p.X = dxb; p.ldx = D; p.ln_part_in = dpart; p.ln_eps = 1e-6f; p.Wp = dwp; p.c1 = dc1; p.s1 = ds1; p.b2 = db2;
         p.resid = dx; p.ldr = D; p.out = dy; p.ldo = D; p.xb = dxb_f; p.ldxb = D; p.ln_part_out = dpart_f; p.M = M; p.D = D; p.Mlp = Mlp; p.f16 = f16; p.split = split; p.stats_out = stats;
         CK(launch_mlp_fused(p, st));
     };
@@ -137,11 +140,11 @@ int main(int argc, char** argv) {
     if (mode == 0 && D == 768) {   // ablations of the bf16 ViT-B kernel + section stamps
         unsigned long long* dst; const int nwg = ceil_div(M, 64);
         CK(hipMalloc(&dst, (size_t)nwg * 8 * 8)); CK(hipMemset(dst, 0, (size_t)nwg * 8 * 8));
-        const int lds = 12 * 8192 + 4 * 16384;
+        const int lds = 12 * 8192 + 2 * 16384;
         auto study = [&](auto kern, const char* name, bool stamps) {
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             MlpFusedParams p{};
-            p.X = dxb; p.ldx = D; p.ln_part_in = dpart; p.ln_eps = 1e-6f; p.W1 = dw1; p.ldw1 = ldw1; p.c1 = dc1; p.s1 = ds1; p.W2 = dw2; p.ldw2 = ldw2; p.b2 = db2;
+            p.X = dxb; p.ldx = D; p.ln_part_in = dpart; p.ln_eps = 1e-6f; p.Wp = dwp; p.c1 = dc1; p.s1 = ds1; p.b2 = db2;
             p.resid = dx; p.ldr = D; p.out = dy; p.ldo = D; p.xb = dxb_f; p.ldxb = D; p.ln_part_out = dpart_f; p.M = M; p.D = D; p.Mlp = Mlp; p.stats_out = 1;
             p.stamps = stamps ? dst : nullptr;
             std::vector<float> t;
@@ -167,15 +170,13 @@ int main(int argc, char** argv) {
             }
         };
         study(mlpf_study_bf16<0>, "study build, as the product", true);
-        study(mlpf_study_bf16<1>, "no DMA inside the loop", false);
+        study(mlpf_study_bf16<1>, "no weight loads inside the loop", false);
         study(mlpf_study_bf16<2>, "no MFMA", false);
         study(mlpf_study_bf16<4>, "no LDS fragment reads", false);
-        study(mlpf_study_bf16<8>, "no s_barrier", false);
-        study(mlpf_study_bf16<5>, "no DMA, no reads (MFMA + sync)", false);
-        study(mlpf_study_bf16<6>, "no MFMA, no reads (DMA + sync)", false);
-        study(mlpf_study_bf16<3>, "no DMA, no MFMA (reads + sync)", false);
-        study(mlpf_study_bf16<7>, "sync skeleton only", true);
-        study(mlpf_study_bf16<15>, "nothing but the epilogue math", false);
+        study(mlpf_study_bf16<5>, "MFMA + epilogues only", false);
+        study(mlpf_study_bf16<6>, "weight loads only", false);
+        study(mlpf_study_bf16<3>, "LDS reads only", false);
+        study(mlpf_study_bf16<7>, "skeleton (phase-1 epilogue + barrier per chunk)", true);
     }
     printf(bad ? "BITWISE MISMATCH\n" : "bitwise identical\n");
     return bad ? 2 : 0;
