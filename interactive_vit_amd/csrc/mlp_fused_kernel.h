@@ -38,9 +38,6 @@ using MlpTile = GemmTile<1, 8, 4, 4>;   // shape constants for the shared epilog
 #ifndef IVIT_MLPF_R
 #define IVIT_MLPF_R 8       // weight blocks (KiB) in flight per wave at D = 768
 #endif
-#ifndef IVIT_MLPF_XSETS
-#define IVIT_MLPF_XSETS 2   // register sets for the X fragments (2: the next K-tile's reads return under this K-tile's MFMAs)
-#endif
 #ifndef IVIT_MLPF_EPI_G
 #define IVIT_MLPF_EPI_G 4   // fragment rows whose residual loads are in flight together in the final epilogue (4 = the whole slot)
 #endif
@@ -171,7 +168,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
         for (int j = 0; j < NHA; ++j) accH[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    bf16x8 xf[IVIT_MLPF_XSETS][4][2] = {};   // X fragments [set = K-tile mod sets][i][kk]
+    bf16x8 xf[2][4][2] = {};   // X fragments [set = K-tile & 1][i][kk]: the next K-tile's reads return under this K-tile's MFMAs
     bf16x8 uf[4][2] = {};      // U fragments of the current hidden half [i][k-step of 32 hidden]
     float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = c4;   // fold vectors of the chunk's hidden columns 16 w + 4 fq ..
     auto read_x = [&](int kt, bf16x8 (&f)[4][2]) {
@@ -193,7 +190,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
         for (int i = 0; i < 4; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // (zeroed here, not after its epilogue: dead, not live, through phase 2)
         mlpf_static_for<P>([&](auto s_tag) {
             constexpr int s = decltype(s_tag)::value, kt = s / SPLIT;
-            if constexpr (IVIT_MLPF_XSETS == 2 && s + 1 < P && (s + 1) % SPLIT == 0) read_x(kt + 1, xf[(kt + 1) & 1]);   // the next K-tile's fragments return under this step's MFMAs
+            if constexpr (s + 1 < P && (s + 1) % SPLIT == 0) read_x(kt + 1, xf[(kt + 1) & 1]);   // the next K-tile's fragments return under this step's MFMAs
             if constexpr (s == UC) {
                 c4 = *reinterpret_cast<const float4*>(p.c1 + c * 128 + 16 * wave + 4 * fq);
                 s4 = *reinterpret_cast<const float4*>(p.s1 + c * 128 + 16 * wave + 4 * fq);
@@ -202,13 +199,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc1[i] = OP::mfma(wq[(2 * s + kk) % R], xf[kt % IVIT_MLPF_XSETS][i][kk], acc1[i]);
+                    for (int i = 0; i < 4; ++i) acc1[i] = OP::mfma(wq[(2 * s + kk) % R], xf[kt & 1][i][kk], acc1[i]);
             } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     asm volatile("" ::"v"(wq[(2 * s + kk) % R]));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(xf[kt % IVIT_MLPF_XSETS][i][kk]));
+                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(xf[kt & 1][i][kk]));
                 }
             }
             if constexpr (!(DBG & 1)) {   // refill the two register slots just consumed: blocks R ahead in the stream.  (Issuing the refill of the PREVIOUS
@@ -216,7 +213,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) wq[(2 * s + kk) % R] = ldw(c, 2 * s + kk + R);   // < CB: phase 2 follows in the same chunk
             }
-            if constexpr (IVIT_MLPF_XSETS == 1 && s + 1 < P && (s + 1) % SPLIT == 0) read_x(kt + 1, xf[0]);
             __builtin_amdgcn_sched_barrier(0);
         });
         // ---------------- phase-1 epilogue (gemm_epilogue_lnfold's arithmetic): u = rn16(gelu(rstd (acc - mean s) + c)), 4 consecutive hidden per lane

@@ -124,7 +124,7 @@ def test_hot_kernels_keep_their_registers(built_lib):
                  # element-guarded EDGE epilogue; now the f32-output kinds are their own "_f32" instantiations and edge tiles guard whole quads)
     seen = 0
     for name, r in res.items():
-        if "ivit_gemm_" not in name and "ivit_attention_" not in name:   # GEMM tiles, one-pass attention, 32-query tiled attention (ivit_attention_q32)
+        if "ivit_gemm_" not in name and "ivit_attention_" not in name and "ivit_mlp_fused_" not in name:   # GEMM tiles, fused MLP, one-pass attention, 32-query tiled attention (ivit_attention_q32)
             continue
         seen += 1
         if "ivit_attention_bf16" in name and "ELb1ENS_" in name and "Li38E" in name:
@@ -134,6 +134,7 @@ def test_hot_kernels_keep_their_registers(built_lib):
         assert r["scratch"] <= limit, (name, r)
     assert seen >= 80
     assert any("ivit_attention_q32" in name for name in res), "the long-sequence attention kernel is not in the library"
+    assert sum("ivit_mlp_fused_" in name for name in res) >= 6, "the fused MLP kernels are not in the library"
     # the budgets the launch geometry assumes: three workgroups of 4 waves per CU (single-stage tiles) need <= 168 VGPRs, two workgroups
     # of 8 waves per CU (attention at <= 224 keys) <= 128
     for name, r in res.items():

@@ -247,10 +247,10 @@ def run_config(model, batch, precision, expect_gemm, expect_fold, layers_to_chec
 
 
 def test_config2_vit_b16_batch64_as_dispatched():
-    """BASELINE configs[1] (the bench default): LayerNorm folded, 160x128 tiles for proj / MLP, 256x256 for QKV."""
+    """BASELINE configs[1] (the bench default): LayerNorm folded, 256x256 for QKV, 160x128 for the out-projection, the fused MLP kernel."""
     run_config("vit_b_16", 64, "bf16",
                {"qkv": "ivit_gemm_bf16_256x256x64_stag_lf", "proj": "ivit_gemm_bf16_160x128x64_rs",
-                "mlp1": "ivit_gemm_bf16_160x128x64_sb_lf", "mlp2": "ivit_gemm_bf16_160x128x64_f32"},   # a layer run alone: no next layer to leave statistics for
+                "mlp": "ivit_mlp_fused_bf16_d768"},   # MLP up + GELU + down + residual in one launch (round 5); the `u` tap of the per-GEMM check runs the two-launch path
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
 
@@ -266,9 +266,9 @@ def test_config4_vit_b16_batch256_as_dispatched():
     """BASELINE configs[3]'s shard (ViT-B/16 B = 2048 over 8 GPUs = 256 images per GPU, 50 432 token rows), gated per GEMM at that
     batch.  What the dispatcher picks there (profiles/r04*_bench_c4.json): the LayerNorm fold stays (2.3 rounds of
     256 x 256 tiles at N = 768: below the 3 rounds at which the residual GEMMs move to that tile), QKV and MLP up take the 256 x 256
-    tile with the fold epilogue (9.9 / 13 rounds), out-projection and MLP down the three-per-CU 160 x 128 tile (1 896 tiles)."""
+    tile with the fold epilogue (9.9 / 13 rounds), out-projection (and MLP down, where the MLP pair is not fused) the three-per-CU 160 x 128 tile."""
     k256, k160 = "ivit_gemm_bf16_256x256x64_stag_lf", "ivit_gemm_bf16_160x128x64_sb"
-    run_config("vit_b_16", 256, "bf16", {"qkv": k256, "proj": k160 + "_rs", "mlp1": k256, "mlp2": k160 + "_f32"},   # a layer run alone: no next layer to leave statistics for
+    run_config("vit_b_16", 256, "bf16", {"qkv": k256, "proj": k160 + "_rs", "mlp": "ivit_mlp_fused_bf16_d768"},   # round 5: the MLP pair in one launch (788 workgroups = 3.08 rounds of 256)
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
 
@@ -419,8 +419,7 @@ def test_config2_vit_b16_batch64_f16_as_dispatched():
     """The same shapes on the f16 data path (IVIT_PRECISION_F16): f16 instantiations of the same tiles, every step gated on
     identical operand bytes (one unit of f16 = 2^-11: eight times finer than the bf16 gate)."""
     run_config("vit_b_16", 64, "f16",
-               {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs",
-                "mlp1": "ivit_gemm_f16_160x128x64_sb_lf", "mlp2": "ivit_gemm_f16_160x128x64_f32"},
+               {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs", "mlp": "ivit_mlp_fused_f16_d768"},
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
 
@@ -428,8 +427,7 @@ def test_config2_vit_b16_batch64_f16x_as_dispatched():
     """IVIT_PRECISION_F16X at the bench batch: the out-projection on hi + lo pairs of both operands, MLP up / down on hi + lo weight
     pairs - every step gated on the engine's own operand bytes (the attention tap carries [hi | lo])."""
     run_config("vit_b_16", 64, "f16x",
-               {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs",
-                "mlp1": "ivit_gemm_f16_160x128x64_sb_lf", "mlp2": "ivit_gemm_f16_160x128x64_f32"},
+               {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs", "mlp": "ivit_mlp_fused_f16x_d768"},
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
 

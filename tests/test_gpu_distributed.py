@@ -59,7 +59,7 @@ def test_bench_json_contract_single_gpu():
         assert rec["vs_rounding_oracle"] <= 1e-3 and rec["vs_plain_f32"] <= 3.5e-3, (node, rec)
     # the additions of round 2: per-kernel roofline list, step-time distribution, PCIe-inclusive rate, device facts
     names = [k["kernel"] for k in rf["kernels"]]
-    assert any(n.startswith("mlp1:ivit_gemm_bf16") for n in names) and any(n.startswith("attention") for n in names), names
+    assert any(n.startswith("mlp:ivit_mlp_fused_bf16") for n in names) and any(n.startswith("attention") for n in names), names
     assert all(0.0 < k["frac"] < 1.0 for k in rf["kernels"] if "frac" in k)
     assert rf["device"]["compute_units"] >= 1
     sm = d["step_ms"]

@@ -283,6 +283,42 @@ def test_vit_b16_batch_parity_and_properties():
         eng.close()
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16", "f16x"])
+def test_fused_mlp_is_bit_identical_to_the_two_gemm_launches(precision, monkeypatch):
+    """The fused MLP kernel (csrc/mlp_fused_kernel.h: LN2-fold -> up -> GELU -> down -> residual -> statistics in one launch, weights streamed from a
+    packed fragment-native copy) against the two GEMM launches it replaces, through the C ABI: the same engine configuration with IVIT_FUSED_MLP=0 / 1
+    must give the same BYTES - a single layer node (no statistics for a next layer), the whole forward (statistics pairs and 16-bit copies chained
+    through twelve layers), at the bench batch (197 full workgroups) and at a batch whose last workgroup is ragged.  The dispatched kernels are asserted."""
+    from interactive_vit_amd.engine import Engine
+    cfg = VARIANTS["vit_b_16"]
+    sd = init_weights(cfg, seed=0, mode="rich")
+    x = synthetic_images(64, cfg, seed=11).cuda()
+    outs = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("IVIT_FUSED_MLP", fused)
+        eng = Engine(cfg, sd, device=0, max_batch=64, precision=precision)
+        try:
+            tok = eng.forward(x, 0, 3)                                     # [B, N, D] token stream
+            eng.profile(True); eng.profile_reset()
+            layer = eng.run_node("encoder.layers.5", tok)
+            logits = eng.forward(x, 0, len(eng.stages))
+            kern = eng.profile_kernels()
+            eng.profile(False)
+            has_fused = any(k.startswith("mlp:ivit_mlp_fused_") for k in kern)
+            assert has_fused == (fused == "1"), sorted(kern)
+            if fused == "1":
+                assert not any(k.startswith("mlp1:") or k.startswith("mlp2:") for k in kern), sorted(kern)
+            ragged = eng.forward(x[:63].contiguous(), 0, len(eng.stages))   # 12 411 token rows: the last workgroup has 59 of its 64 rows
+            one = eng.forward(x[:1].contiguous(), 0, len(eng.stages))       # the interactive path: never fused
+            outs[fused] = (layer, logits, ragged, one)
+        finally:
+            eng.close()
+    for a, b, what in zip(outs["0"], outs["1"], ("layer node", "forward", "ragged forward", "one image")):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), f"{precision}: {what} differs between the fused MLP kernel and the two GEMM launches"
+    assert torch.equal(outs["1"][3][0], outs["1"][1][0]), "image 0 alone (GEMM pair on small tiles) != image 0 in the batch (fused kernel)"
+
+
 def test_vit_l16_384_long_sequence():
     """BASELINE config 3 shapes (ViT-L/16 at 384^2: 577 tokens, D = 1024, 16 heads): the attention
     kernel's 16-queries-per-wave / 608-key instantiation, LayerNorm<4>, K = 1024/4096 GEMMs.  The CPU
@@ -838,7 +874,7 @@ def test_f16_vit_b16_batch64_nodes_and_chain(precision, chain_tol):
         eng.profile(True); eng.profile_reset()
         out0 = eng.run_node("encoder.layers.0", tok.cuda())
         kern = eng.profile_kernels(); eng.profile(False)
-        assert any(k.startswith("qkv:ivit_gemm_f16_") for k in kern) and any(k.startswith("mlp1:ivit_gemm_f16_") for k in kern), sorted(kern)
+        assert any(k.startswith("qkv:ivit_gemm_f16_") for k in kern) and any(k.startswith("mlp:ivit_mlp_fused_f16") for k in kern), sorted(kern)
         vit_oracle.LN_FOLD = eng.ln_fold_for(64)
         e32 = rel_err(out0[:2], acts["encoder.layers.0"])
         emu = rel_err(out0[:2], vit_oracle.run_node("encoder.layers.0", tok[:2].double(), sd, cfg, emulate=True))
