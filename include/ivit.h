@@ -217,7 +217,10 @@ int ivit_allgather_cls(ivit_engine* e, const void* send, void* recv, int64_t flo
  * ivit_shard_layout: the shard rule (rank r of `world` holds rows [begin, begin + rows) of `total`, the first total % world ranks one row
  * more; padded_rows = the largest shard) - host arithmetic, no GPU.
  * ivit_allgather_rows: ONE ncclAllGather of every rank's [rows_local, row_floats] block into recv [total_rows, row_floats] in image order;
- * ragged shards (total_rows % world != 0) are padded to padded_rows inside the engine for the collective and compacted afterwards. */
+ * ragged shards (total_rows % world != 0) are padded to padded_rows inside the engine for the collective and compacted afterwards (staging sized at
+ * ivit_comm_init for max_batch packed rows per rank; wider rows grow it behind a device synchronise).  A rank whose shard is empty (total_rows <
+ * world) passes rows_local = 0 and may pass send = NULL; it still takes part in the collective.  A non-zero return on ANY rank (argument check,
+ * allocation) means that rank did not enter the collective: its peers block in theirs - treat it as fatal for the communicator. */
 int ivit_forward_device_packed(ivit_engine* e, int stage_begin, int batch, const void* in, void* packed, int64_t row_stride, void* stream);
 int ivit_shard_layout(int64_t total, int world, int rank, int64_t* begin, int64_t* rows, int64_t* padded_rows);
 int ivit_allgather_rows(ivit_engine* e, const void* send, int64_t rows_local, int64_t row_floats, int64_t total_rows, void* recv, void* stream);

@@ -1535,6 +1535,13 @@ extern "C" int ivit_comm_init(ivit_engine* e, const void* id128, int rank, int w
     const int rc = g_rccl.comm_init_rank(&comm, world, id, rank);
     if (rc != 0) return fail("ncclCommInitRank failed: %s", g_rccl.error_string(rc));
     e->comm = comm; e->comm_rank = rank; e->comm_world = world;
+    // staging of ivit_allgather_rows for ragged shards, sized here once for the step's packed [logits | class features] rows (max_batch per rank): no
+    // allocation on the step path (padded block | the world's padded blocks)
+    if (world > 1 && !e->gather_buf) {
+        const size_t pad_bytes = (size_t)e->cfg.max_batch * (e->cfg.classes + e->D) * 4;
+        HIP_TRY(hipMalloc((void**)&e->gather_buf, pad_bytes * (world + 1)));
+        e->gather_bytes = pad_bytes * (world + 1);
+    }
     return 0;
 }
 
@@ -1561,7 +1568,7 @@ extern "C" int ivit_shard_layout(int64_t total, int world, int rank, int64_t* be
 }
 
 extern "C" int ivit_allgather_rows(ivit_engine* e, const void* send, int64_t rows_local, int64_t row_floats, int64_t total_rows, void* recv, void* stream) {
-    if (!e || !send || !recv) return fail("ivit_allgather_rows: null argument");
+    if (!e || !recv || (!send && rows_local != 0)) return fail("ivit_allgather_rows: null argument");   // a rank whose shard is empty (total_rows < world) may pass send = nullptr
     if (rows_local < 0 || row_floats <= 0 || total_rows <= 0) return fail("ivit_allgather_rows: nothing to gather");
     std::lock_guard<std::mutex> lk(e->mu);
     if (!e->comm) return fail("ivit_allgather_rows: no communicator (call ivit_comm_init on every rank first)");
@@ -1570,22 +1577,26 @@ extern "C" int ivit_allgather_rows(ivit_engine* e, const void* send, int64_t row
     int64_t begin = 0, mine = 0, big = 0;
     if (ivit_shard_layout(total_rows, e->comm_world, e->comm_rank, &begin, &mine, &big)) return 1;
     if (mine != rows_local) return fail("ivit_allgather_rows: rank %d holds %lld rows, its shard of %lld over %d ranks is %lld", e->comm_rank, (long long)rows_local, (long long)total_rows, e->comm_world, (long long)mine);
+    // Everything that can fail on THIS rank alone lies above and directly below: a rank that returns before the collective leaves its peers blocked
+    // inside theirs (a failure of this call on any rank is fatal for the communicator - include/ivit.h).
     if (total_rows % e->comm_world == 0) {   // equal shards: straight into the caller's buffer
         const int rc = g_rccl.all_gather(send, recv, (size_t)(rows_local * row_floats), kRcclFloat32, e->comm, st);
         if (rc != 0) return fail("ncclAllGather failed: %s", g_rccl.error_string(rc));
         return 0;
     }
     // ragged shards: every rank's block padded to the largest shard for the ONE collective, compacted afterwards (the rule of
-    // sharding.all_gather_outputs); the staging buffers are the engine's, grown on demand
+    // sharding.all_gather_outputs).  The staging is the engine's: sized at ivit_comm_init for the packed [logits | class features] rows of max_batch
+    // images per rank, grown here only for wider rows (the patch outputs of the interactive view) - behind a device-wide synchronise, because an
+    // earlier gather on ANOTHER stream may still be using the old buffer.
     const size_t pad_bytes = (size_t)big * row_floats * 4, all_bytes = pad_bytes * e->comm_world;
     if (e->gather_bytes < pad_bytes + all_bytes) {
-        if (e->gather_buf) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(e->gather_buf)); e->gather_buf = nullptr; e->gather_bytes = 0; }
+        if (e->gather_buf) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(e->gather_buf)); e->gather_buf = nullptr; e->gather_bytes = 0; }
         HIP_TRY(hipMalloc((void**)&e->gather_buf, pad_bytes + all_bytes));
         e->gather_bytes = pad_bytes + all_bytes;
     }
     char* pad = e->gather_buf, *all = e->gather_buf + pad_bytes;
     HIP_TRY(hipMemsetAsync(pad, 0, pad_bytes, st));
-    HIP_TRY(hipMemcpyAsync(pad, send, (size_t)rows_local * row_floats * 4, hipMemcpyDeviceToDevice, st));
+    if (rows_local) HIP_TRY(hipMemcpyAsync(pad, send, (size_t)rows_local * row_floats * 4, hipMemcpyDeviceToDevice, st));
     const int rc = g_rccl.all_gather(pad, all, (size_t)(big * row_floats), kRcclFloat32, e->comm, st);
     if (rc != 0) return fail("ncclAllGather failed: %s", g_rccl.error_string(rc));
     for (int r = 0; r < e->comm_world; ++r) {

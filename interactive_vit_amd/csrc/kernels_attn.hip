@@ -510,18 +510,23 @@ __global__ __launch_bounds__(MAXW * 64) void ivit_attention_q32(AttnParams p, in
         pair_exchange(fmaxf(fmaxf(ta, tb), fmaxf(a[14], a[15])), xa, xb);
         return fmaxf(xa, xb);
     };
-    int npad = 0;   // how many of this lane's 16 keys of the LAST tile lie past N
-    {
-        const int lim = N - 32 * (nt - 1) - 4 * hi;
+    // Keys past N (the last key tile: zero K rows, so they would score exactly 0).  They are MASKED - their scores become -inf, their numerators exactly 0 - in
+    // that one tile.  (Round 4 let them through and subtracted their npad x rn16(2^-m) from the row sum afterwards: for a row whose real logits are all far
+    // below 0 the reference exponent m is very negative, those terms swamp the f32 sum and the subtraction cancels - 4e-4 at logits of -20, 41 % at -28 -
+    // and 2^-m leaves the f16 range altogether; a softmax must not depend on where 0 lies.)  This lane's 16 keys of a tile: (r & 3) + 8 (r >> 2) + 4 hi.
+    const int pad_lim = N - 32 * (nt - 1) - 4 * hi;
+    const bool pad_any = (N & 31) != 0;
+    auto mask_last = [&](f32x16& a) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) npad += ((r & 3) + 8 * (r >> 2) >= lim) ? 1 : 0;
-    }
+        for (int r = 0; r < 16; ++r) a[r] = ((r & 3) + 8 * (r >> 2) >= pad_lim) ? -INFINITY : a[r];
+    };
     f32x16 o0, o1;
     float m_row, sum;   // sum: this lane's half of the row sum
     // key tiles [t0, t1) of the query block in qf -> o0, o1, sum, m_row
     auto tiles = [&](int t0, int t1) {
         f32x16 s;
-        auto body = [&](int off) {   // the tile at vp + off (its scores are in s), then the scores of the tile after it
+        auto body = [&](int off, auto mask_tag) {   // the tile at vp + off (its scores are in s; mask_tag: it is the tile with the padded keys), then the scores of the tile after it
+            if (decltype(mask_tag)::value) mask_last(s);
             union { bf16x8 v; bf16x4 h2[2]; } vf[2][2];
 #pragma unroll
             for (int st = 0; st < 2; ++st)
@@ -554,13 +559,17 @@ __global__ __launch_bounds__(MAXW * 64) void ivit_attention_q32(AttnParams p, in
             sum = 0.f;
             set_tile(t0);
             qk(s, 0);
-            if (pass == 0) m_row = ceilf(row_max(s) * cexp);
-            int rem = t1 - t0;
+            const bool tail = pad_any && t1 == nt;   // the slice ends on the tile with the padded keys: that tile runs the masking form of the body (wave-uniform)
+            if (pass == 0) {
+                if (tail && t1 - t0 == 1) mask_last(s);   // (idempotent: the body masks it again)
+                m_row = ceilf(row_max(s) * cexp);
+            }
+            int rem = t1 - t0 - (tail ? 1 : 0);
             if (MAXW <= 12) {   // (two tiles a turn where the register budget allows: 3 waves per SIMD, 170 registers)
 #pragma unroll 1
                 for (; rem >= 2; rem -= 2) {
-                    body(0);
-                    body(L::TILE);
+                    body(0, std::false_type{});
+                    body(L::TILE, std::false_type{});
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) kp[kk] += 2 * L::TILE;
                     vp[0] += 2 * L::TILE; vp[1] += 2 * L::TILE;
@@ -568,22 +577,28 @@ __global__ __launch_bounds__(MAXW * 64) void ivit_attention_q32(AttnParams p, in
             }
 #pragma unroll 1
             for (; rem >= 1; --rem) {
-                body(0);
+                body(0, std::false_type{});
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) kp[kk] += L::TILE;
                 vp[0] += L::TILE; vp[1] += L::TILE;
             }
-            if (t1 == nt) sum -= (float)npad * OP::to_f32(OP::from_f32(__builtin_amdgcn_exp2f(-m_row)));   // the keys past N: score 0, numerator rn16(2^-m) each
+            if (tail) {
+                body(0, std::true_type{});
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) kp[kk] += L::TILE;
+                vp[0] += L::TILE; vp[1] += L::TILE;
+            }
             if (pass == 1) break;
             float sa, sb;
             pair_exchange(sum, sa, sb);
             const bool bad = !(fabsf(sa + sb) < INFINITY);   // a numerator left the 16-bit range (or the input was not finite)
             if (__builtin_amdgcn_ballot_w64(bad) == 0) break;
-            float mx = -INFINITY;   // the true maximum of the slice, for the rows that need it (padded keys count as 0: harmless, m is only a reference)
+            float mx = -INFINITY;   // the true maximum of the slice over its REAL keys, for the rows that need it
             set_tile(t0);
 #pragma unroll 1
             for (int t = t0; t < t1; ++t) {
                 qk(s, 0);
+                if (tail && t == t1 - 1) mask_last(s);
                 mx = fmaxf(mx, row_max(s));
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) kp[kk] += L::TILE;
@@ -912,6 +927,8 @@ const char* attention_kernel_name(const AttnParams& p) { return use_q32(p) ? "iv
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (!attention_supported(p.tokens, p.head_dim)) return hipErrorInvalidValue;
     if ((p.ldqkv % 8) || (!p.probs && !p.out8 && (p.ldo % 4)) || (p.out8 && (p.ldo8 % 4))) return hipErrorInvalidValue;
+    // the 16-bit output goes out in 16-byte stores (the one-pass kernel below 38 key fragments, ivit_attention_q32's store_block): rows and base 16-byte aligned
+    if (!p.probs && !p.out8 && !p.lo_off && ((p.ldo % 8) || (reinterpret_cast<uintptr_t>(p.out) & 15))) return hipErrorInvalidValue;
     const int nkf = round_up(ceil_div(p.tokens, 16), 2);
     if (use_q32(p)) {
 #ifdef IVIT_GEMM_ABLATIONS

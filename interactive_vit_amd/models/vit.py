@@ -190,6 +190,20 @@ class HipBackend:
             if images.dim() == 3:
                 images = images.unsqueeze(0)
             self.ln_fold_ratio = self.engine.calibrate_ln_fold(images[:max_batch], threshold=ln_fold_threshold)
+        # The e4m3 data paths need their static activation scales before any layer node can run (engine: "fp8 engine is not calibrated"): the plugin
+        # calibrates them here, on the operator's sample pictures when there are some (nothing in the plugin path ever did, so every layer node
+        # of an IVIT_PRECISION=fp8 / fp8m deployment returned that message).
+        self.fp8_scales = None
+        if precision in ("fp8", "fp8m"):
+            import logging
+            if calibration_images is None:
+                logging.getLogger(__name__).warning(
+                    "%s: e4m3 activation scales calibrated on %d seeded SYNTHETIC images (no calibration_images given); pass real sample pictures to "
+                    "HipBackend / build_plugins", cfg.name, min(2, max_batch))
+            images = calibration_images if calibration_images is not None else synthetic_images(min(2, max_batch), cfg, seed=7)
+            if images.dim() == 3:
+                images = images.unsqueeze(0)
+            self.fp8_scales = self.engine.calibrate_fp8(images[:max_batch])
 
     def module(self) -> torch.nn.Module:
         return self._module

@@ -441,6 +441,52 @@ def test_long_sequence_attention_redo_when_a_late_key_dominates(precision):
         eng.close()
 
 
+@pytest.mark.parametrize("image,tokens", [(384, 577), (368, 530)])
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_long_sequence_attention_rows_far_below_zero(image, tokens, precision):
+    """ivit_attention_q32 let the keys past N (zero K rows: score exactly 0) through the tile loop and subtracted their numerators from the
+    row sum afterwards - a softmax that depended on where 0 lies: for a row whose real logits are all around -32 nats the padded terms are 2^46 each
+    (they swamp the f32 sum; in f16 they are infinite and the redo pass, whose maximum counted the padded zeros, then flushed every real numerator
+    to 0).  The padded keys are masked now.  Every query's logits here lie within +-2 nats of -32 (q and k mostly bias): the layer must match the
+    shift-invariant oracle at 577 tokens (31 padded keys in the last tile) and 530 (14)."""
+    from interactive_vit_amd.engine import Engine
+    from oracle import vit_oracle
+    cfg = small_config(name=f"vit_test_long{tokens}", image=image, patch=16, dim=128, heads=2, layers=1, mlp=256, classes=16)
+    assert cfg.tokens == tokens and vit_oracle.engine_attention_form(cfg.tokens, cfg.head_dim) == "q32"
+    sd = init_weights(cfg, seed=13, mode="rich")
+    pre = "encoder.layers.encoder_layer_0."
+    d = cfg.dim
+    w_in, b_in = sd[pre + "self_attention.in_proj_weight"].clone(), sd[pre + "self_attention.in_proj_bias"].clone()
+    w_in[: 2 * d] *= 0.25                       # q, k: a little of the input ...
+    b_in[:d] = -2.0                             # ... on top of q = -2, k = +2 in every component: q . k / 8 = -4 x 64 / 8 = -32 nats
+    b_in[d: 2 * d] = 2.0
+    sd[pre + "self_attention.in_proj_weight"], sd[pre + "self_attention.in_proj_bias"] = w_in, b_in
+    g = torch.Generator().manual_seed(5)
+    tok = torch.randn(2, cfg.tokens, d, generator=g)
+    eng = Engine(cfg, sd, device=0, max_batch=2, precision=precision)
+    try:
+        vit_oracle.OPERAND_DTYPE = eng.operand_dtype
+        vit_oracle.SPLIT_GEMMS = eng.split_gemms
+        vit_oracle.LN_FOLD = eng.ln_fold
+        qkv = vit_oracle.layer_norm(tok.double(), sd[pre + "ln_1.weight"].double(), sd[pre + "ln_1.bias"].double(), cfg.ln_eps) @ w_in.double().t() + b_in.double()
+        q, k = qkv[..., :d].reshape(2, -1, cfg.heads, 64).transpose(1, 2), qkv[..., d:2 * d].reshape(2, -1, cfg.heads, 64).transpose(1, 2)
+        sc = q @ k.transpose(-1, -2) / 8.0
+        assert float(sc.max()) < -20.0, float(sc.max())        # the construction does what it says: every logit far below 0
+        eng.profile(True); eng.profile_reset()
+        got = eng.run_node("encoder.layers.0", tok.cuda()).cpu()
+        kern = eng.profile_kernels(); eng.profile(False)
+        assert "attention:ivit_attention_q32" in kern, sorted(kern)
+        assert torch.isfinite(got).all()
+        emu = vit_oracle.run_node("encoder.layers.0", tok.double(), sd, cfg, emulate=True)
+        err = rel_err(got, emu)
+        print(f"{cfg.name} {precision}: logits in [{float(sc.min()):.1f}, {float(sc.max()):.1f}] nats, layer vs rounding-aware oracle {err:.2e}")
+        assert err <= REL_TOL
+    finally:
+        vit_oracle.OPERAND_DTYPE = torch.bfloat16
+        vit_oracle.SPLIT_GEMMS = frozenset()
+        eng.close()
+
+
 def test_attention_map_nodes(small):
     """`encoder.layers.<i>.attn`: [N,D] -> [heads,N,N] attention probabilities."""
     from oracle import vit_oracle
