@@ -134,6 +134,32 @@ def test_emulate_mode_is_plain_mode_plus_bf16_rounding():
     assert torch.equal(w, w.to(torch.bfloat16).to(torch.float64))
 
 
+@pytest.mark.parametrize("ln_fold", [False, True])
+def test_emulate_mode_with_every_rounding_point_off_is_the_plain_forward(ln_fold):
+    """the rounding-aware mode is what every per-node GPU gate compares against, so it must be "the plain forward + roundings" and
+    nothing else.  With every rounding point switched off (ROUND_ONLY = empty set) the emulate path - LayerNorm fold algebra, the engine's softmax
+    forms, fused patch / token arithmetic - must reproduce the plain float64 forward to round-off, node by node."""
+    cfg = small_config()
+    sd = init_weights(cfg, seed=3, mode="rich")
+    x = synthetic_images(2, cfg, seed=5).double()
+    plain = vo.forward(x, sd, cfg, keep=True)
+    order = vo.node_suffixes(cfg)
+    saved = (vo.ROUND_ONLY, vo.LN_FOLD)
+    try:
+        vo.ROUND_ONLY, vo.LN_FOLD = frozenset(), ln_fold
+        chain = vo.forward(x, sd, cfg, keep=True, emulate=True)
+        for i, node in enumerate(order):
+            node_in = x if i == 0 else plain[order[i - 1]]
+            emu = vo.run_node(node, node_in, sd, cfg, emulate=True)
+            err = float((plain[node] - emu).abs().max() / plain[node].abs().max())
+            assert err <= 1e-12, (node, err)
+    finally:
+        vo.ROUND_ONLY, vo.LN_FOLD = saved
+    # the whole chain: the emulate forward evaluates the transform in float32, as the engine does (3 flops per element) - the only difference left
+    err = float((plain["logits"] - chain["logits"]).abs().max() / plain["logits"].abs().max())
+    assert err <= 1e-6, err
+
+
 def test_seeded_weights_and_image_are_pinned():
     cfg = VARIANTS[VGOLD["config"]]
     sd = init_weights(cfg, seed=VGOLD["weights"]["seed"], mode=VGOLD["weights"]["mode"])
