@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define IVIT_ABI_VERSION 9
+#define IVIT_ABI_VERSION 10
 
 #define IVIT_PRECISION_BF16 0   /* bf16 GEMM operands (default) */
 #define IVIT_PRECISION_FP8  1   /* encoder GEMMs on e4m3 weights + activations (BASELINE config 5); needs ivit_fp8_calibrate */
@@ -111,6 +111,18 @@ int ivit_weights_ready(ivit_engine* e);
  * kernel.  Both forms are bf16 evaluations of the same f32 contract with different rounding points; the parity tests
  * ask which one the oracle's rounding-aware mode has to mirror. */
 int ivit_ln_fold(const ivit_engine* e, int batch);
+
+/* 0 when the MLP of a forward of `batch` images runs as two GEMM launches (MLP up + GELU, MLP down + residual); else the form of the fused MLP
+ * kernel it runs as (csrc/mlp_fused_kernel.h: LayerNorm fold, up, GELU, down, residual and the next layer's statistics in one launch; round 5):
+ * 1 plain 16-bit weights; 2 both weight matrices as hi / lo pairs (IVIT_PRECISION_F16X with IVIT_F16X_MLP2=1), 3 the up weight only
+ * (IVIT_PRECISION_F16X's default).  Every form is BIT-IDENTICAL to the two launches on the same operands.  The fused kernel takes the calls whose
+ * 64-row workgroups fill the chip (dim 512 / 768, LayerNorm fold on; IVIT_FUSED_MLP=0 disables it). */
+int ivit_fused_mlp(const ivit_engine* e, int batch);
+
+/* Which GEMMs of this engine multiply hi / lo pairs of f16 values (IVIT_PRECISION_F16 / F16X; 0 for the other precisions): bit 0 patch embedding and
+ * classifier head (both operands), bit 1 the out-projection (both operands; IVIT_F16X_PROJ=0 drops it), bit 2 the MLP-up weight, bit 3 the MLP-down
+ * weight (by default only where the fused MLP kernel cannot run - dim other than 512 / 768; IVIT_F16X_MLP2=0 / 1 overrides). */
+int ivit_split_set(const ivit_engine* e);
 
 /* Guard of the LayerNorm fold for a weight set.  The folded GEMM multiplies the UNCENTRED 16-bit copy of the residual
  * stream, so its operand-rounding noise is sqrt(1 + (mean/std)^2) times the unfolded form's, mean / std taken per

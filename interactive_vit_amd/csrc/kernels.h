@@ -96,7 +96,7 @@ struct MlpFusedParams {
     float2* ln_part_out;                 // stats_out: their pairs (may alias ln_part_in)
     int M, D, Mlp;
     int f16;                             // 0: bf16 operands, 1: IEEE f16
-    int split;                           // 0, or 1: the weights are hi / lo pairs (IVIT_PRECISION_F16X)
+    int split;                           // 0; 1: both weight matrices are hi / lo pairs; 2: only the up weight (IVIT_PRECISION_F16X's default split set)
     int stats_out;                       // 1: EPI_BIAS_RESID_STATS semantics, 0: EPI_BIAS_RESID_F32
     unsigned long long* stamps;          // microbenchmark builds only
 };

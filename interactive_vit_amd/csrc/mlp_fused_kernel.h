@@ -41,15 +41,15 @@ using MlpTile = GemmTile<1, 8, 4, 4>;   // shape constants for the shared epilog
 #ifndef IVIT_MLPF_EPI_G
 #define IVIT_MLPF_EPI_G 4   // fragment rows whose residual loads are in flight together in the final epilogue (4 = the whole slot)
 #endif
-template <int ND_, int SPLIT_>
+template <int ND_, int S1_, int S2_>
 struct MlpFusedGeom {
-    static constexpr int ND = ND_, SPLIT = SPLIT_;
+    static constexpr int ND = ND_, S1 = S1_, S2 = S2_;   // S1 / S2 = 2: W1' / W2 are hi / lo pairs of 16-bit values (K-tiles interleaved), else 1
     static constexpr int BM = 64, HC = 128, THREADS = 512;
-    static constexpr int P = ND * SPLIT;            // phase-1 steps per chunk (one 64-deep K-tile of W1' each; split: hi / lo alternate)
+    static constexpr int P = ND * S1;               // phase-1 steps per chunk (one 64-deep K-tile of W1' each; split: hi / lo alternate)
     static constexpr int NF = ND / 2;               // output column fragments per wave (D / 8 columns)
     static constexpr int NH = NF - 4;               // ... of which the last NH belong to the shared slot (0 at D = 512, 2 at D = 768)
     static constexpr int P2 = 2 * NF;               // phase-2 steps per chunk: two passes (hidden halves of 64) over the NF column fragments
-    static constexpr int NB1 = 2 * P, NB2 = 2 * SPLIT * P2; // 1-KiB fragment blocks per wave and chunk
+    static constexpr int NB1 = 2 * P, NB2 = 2 * S2 * P2;  // 1-KiB fragment blocks per wave and chunk
     static constexpr int CB = NB1 + NB2;            // = 48 (96 split) at D = 768
     static constexpr int R = (ND == 12 ? IVIT_MLPF_R : 8);   // blocks in flight per wave (4 VGPRs each)
     static constexpr int X_BYTES = ND * 8192, U_BYTES = 16384, LDS_BYTES = X_BYTES + 2 * U_BYTES;
@@ -61,19 +61,19 @@ struct MlpFusedGeom {
 // where block b of wave w's stream for chunk c comes from (host + device: the pack kernel and its tests)
 // phase 1 (b < NB1): K-tile s = b / 2 of W1' (split: K-tiles alternate hi / lo), 32-deep half kk = b % 2: rows c * 128 + 16 w + [0, 16)
 // phase 2: hidden half h (64 of the chunk's 128; split: hidden K-tile 2 c + h), column fragment t, q: unsplit k-step q of 32 hidden; split hi (q < 2) / lo, kk = q & 1
-template <int ND, int SPLIT>
+template <int ND, int S1, int S2>
 __host__ __device__ inline void mlpf_block_source(int c, int w, int b, int lane, bool* is_w1, int* row, int* col) {
-    using G = MlpFusedGeom<ND, SPLIT>;
+    using G = MlpFusedGeom<ND, S1, S2>;
     const int r16 = lane & 15, kc = lane >> 4;
     if (b < G::NB1) {
         *is_w1 = true;
         *row = c * 128 + 16 * w + r16;
         *col = (b >> 1) * 64 + (b & 1) * 32 + 8 * kc;
     } else {
-        const int b2 = b - G::NB1, h = b2 / (G::NF * 2 * SPLIT), rem = b2 % (G::NF * 2 * SPLIT), t = rem / (2 * SPLIT), q = rem % (2 * SPLIT);
+        const int b2 = b - G::NB1, h = b2 / (G::NF * 2 * S2), rem = b2 % (G::NF * 2 * S2), t = rem / (2 * S2), q = rem % (2 * S2);
         *is_w1 = false;
         *row = (t < 4 ? 64 * w + 16 * t : 64 * (8 + (w >> 1)) + 32 * (w & 1) + 16 * (t - 4)) + r16;
-        *col = SPLIT == 1 ? c * 128 + 64 * h + 32 * q + 8 * kc : (2 * c + h) * 128 + (q >> 1) * 64 + (q & 1) * 32 + 8 * kc;
+        *col = S2 == 1 ? c * 128 + 64 * h + 32 * q + 8 * kc : (2 * c + h) * 128 + (q >> 1) * 64 + (q & 1) * 32 + 8 * kc;
     }
 }
 
@@ -102,9 +102,9 @@ __device__ __forceinline__ void mlpf_static_for(F&& f) { mlpf_static_for_impl(f,
 
 // DBG (tools/mlp_fused_bench only; 0 in the product): timing ablations, a bit mask - 1 = no weight loads inside the loop, 2 = no MFMA,
 // 4 = no LDS fragment reads (results are wrong in every ablation; only the time is read)
-template <int ND, int SPLIT, class OP, int DBG = 0>
+template <int ND, int S1, int S2, class OP, int DBG = 0>
 __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* smem) {
-    using G = MlpFusedGeom<ND, SPLIT>;
+    using G = MlpFusedGeom<ND, S1, S2>;
     using T = MlpTile;
     constexpr int P = G::P, P2 = G::P2, NB1 = G::NB1, CB = G::CB, R = G::R, NH = G::NH, UC = G::UC;
     const int lane = threadIdx.x & 63;
@@ -189,8 +189,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // (zeroed here, not after its epilogue: dead, not live, through phase 2)
         mlpf_static_for<P>([&](auto s_tag) {
-            constexpr int s = decltype(s_tag)::value, kt = s / SPLIT;
-            if constexpr (s + 1 < P && (s + 1) % SPLIT == 0) read_x(kt + 1, xf[(kt + 1) & 1]);   // the next K-tile's fragments return under this step's MFMAs
+            constexpr int s = decltype(s_tag)::value, kt = s / S1;
+            if constexpr (s + 1 < P && (s + 1) % S1 == 0) read_x(kt + 1, xf[(kt + 1) & 1]);   // the next K-tile's fragments return under this step's MFMAs
             if constexpr (s == UC) {
                 c4 = *reinterpret_cast<const float4*>(p.c1 + c * 128 + 16 * wave + 4 * fq);
                 s4 = *reinterpret_cast<const float4*>(p.s1 + c * 128 + 16 * wave + 4 * fq);
@@ -252,7 +252,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
         };
         read_u(0);
         mlpf_static_for<P2>([&](auto v_tag) {
-            constexpr int v = decltype(v_tag)::value, t = v % G::NF, NQ = 2 * SPLIT, b0 = NB1 + NQ * v;
+            constexpr int v = decltype(v_tag)::value, t = v % G::NF, NQ = 2 * S2, b0 = NB1 + NQ * v;
             if constexpr (v == G::NF) read_u(1);
             if constexpr (v == P2 - 1) {
                 read_x(0, xf[0]);   // the next chunk's first K-tile
@@ -290,6 +290,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
     for (int b = 0; b < R; ++b) asm volatile("" ::"v"(wq[b]));   // the look-ahead past the last chunk is waited for, not dropped mid-flight
 
     // ---------------- residual epilogue of the MLP-down GEMM
+    // (the row base and the lane's fragment coordinates re-enter through an opaque statement: hipcc otherwise computes the epilogue's row addresses ABOVE the
+    // loop and keeps - or spills - them across it)
+    int m0e = m0, fre = fr, fqe = fq;
+    asm volatile("" : "+s"(m0e), "+v"(fre), "+v"(fqe));
     GemmParams gp{};
     gp.M = p.M; gp.N = p.D; gp.bias = p.b2; gp.resid = p.resid; gp.ldr = p.ldr; gp.out = p.out; gp.ldo = p.ldo;
     gp.xb = p.xb; gp.ldxb = p.ldxb; gp.ln_part = p.ln_part_out;
@@ -303,16 +307,16 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
     if constexpr (NH > 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 16 * i + fr;
+            const int m = m0e + 16 * i + fre;
             row_ok[i] = m < p.M;
-            const float* rs = p.resid + (size_t)(row_ok[i] ? m : p.M - 1) * p.ldr + n0 + 4 * fq;
+            const float* rs = p.resid + (size_t)(row_ok[i] ? m : p.M - 1) * p.ldr + n0 + 4 * fqe;
 #pragma unroll
             for (int j = 0; j < 2; ++j) xh[i][j] = *reinterpret_cast<const float4*>(rs + 16 * j);
         }
     }
     // the wave's own slot: exactly the (FM = 4, FN = 4) epilogue of the GEMM kernels
-    if (p.stats_out) gemm_epilogue_family<T, 1, OP, IVIT_MLPF_EPI_G>(gp, accF, m0, 64 * wave, fr, fq);
-    else gemm_epilogue_family<T, 3, OP, IVIT_MLPF_EPI_G>(gp, accF, m0, 64 * wave, fr, fq);
+    if (p.stats_out) gemm_epilogue_family<T, 1, OP, IVIT_MLPF_EPI_G>(gp, accF, m0e, 64 * wave, fre, fqe);
+    else gemm_epilogue_family<T, 3, OP, IVIT_MLPF_EPI_G>(gp, accF, m0e, 64 * wave, fre, fqe);
     if constexpr (NH > 0) {
         // the shared slot 8 + w / 2: the even wave holds its fragments j = 0, 1, the odd wave j = 2, 3.  Same element arithmetic; the slot's row sum and
         // M2 are the GEMM epilogue's sequential lane sums (j, then r), so the two waves CHAIN them through LDS: even -> odd (sum), odd -> even (slot
@@ -320,11 +324,11 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
         static_assert(NH == 0 || NH == 2, "half of a four-fragment slot");
         float* xch = reinterpret_cast<float*>(ubuf + (nchunks & 1) * G::U_BYTES) + (wave >> 1) * 1024;   // three arrays of [4 i][64 lanes] per wave pair
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bias_h[j] = *reinterpret_cast<const float4*>(p.b2 + n0 + 16 * j + 4 * fq);
+        for (int j = 0; j < 2; ++j) bias_h[j] = *reinterpret_cast<const float4*>(p.b2 + n0 + 16 * j + 4 * fqe);
         float sum[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int mr = row_ok[i] ? m0 + 16 * i + fr : p.M - 1;
+            const int mr = row_ok[i] ? m0e + 16 * i + fre : p.M - 1;
             sum[i] = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -332,13 +336,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
                                     xh[i][j].z + (accH[i][j][2] + bias_h[j].z), xh[i][j].w + (accH[i][j][3] + bias_h[j].w)};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) accH[i][j][r] = v[r];
-                if (row_ok[i]) *reinterpret_cast<float4*>(p.out + (size_t)mr * p.ldo + n0 + 16 * j + 4 * fq) = make_float4(v[0], v[1], v[2], v[3]);
+                if (row_ok[i]) *reinterpret_cast<float4*>(p.out + (size_t)mr * p.ldo + n0 + 16 * j + 4 * fqe) = make_float4(v[0], v[1], v[2], v[3]);
             }
             if (p.stats_out) {   // 16-bit copy: 16-byte stores through the fragment-pair lane swap, as the GEMM epilogue (the swap itself in every lane)
                 const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][0], accH[i][0][1]), OP::pack2(accH[i][1][0], accH[i][1][1]), false, false);
                 const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][2], accH[i][0][3]), OP::pack2(accH[i][1][2], accH[i][1][3]), false, false);
                 u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
-                if (row_ok[i]) *reinterpret_cast<u32x4*>(p.xb + (size_t)mr * p.ldxb + n0 + (fq & 1) * 16 + (fq & ~1) * 4) = pk;
+                if (row_ok[i]) *reinterpret_cast<u32x4*>(p.xb + (size_t)mr * p.ldxb + n0 + (fqe & 1) * 16 + (fqe & ~1) * 4) = pk;
             }
         }
         if (p.stats_out) {   // (uniform branch: every wave takes the same barriers)
@@ -397,7 +401,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
                         for (int r = 0; r < 4; ++r) { const float d = accH[i][j][r] - lmean[i]; q2 = fmaf(d, d, q2); }
                     q2 += __shfl_xor(q2, 16, 64);
                     q2 += __shfl_xor(q2, 32, 64);
-                    if (fq == 0 && row_ok[i]) p.ln_part_out[(size_t)(m0 + 16 * i + fr) * GEMM_LN_SLOTS + hslot] = make_float2(sum[i], q2);
+                    if (fqe == 0 && row_ok[i]) p.ln_part_out[(size_t)(m0e + 16 * i + fre) * GEMM_LN_SLOTS + hslot] = make_float2(sum[i], q2);
                 }
             }
         }

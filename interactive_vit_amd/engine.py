@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
     "ivit_profile_kernel_count", "ivit_profile_kernel_read", "ivit_debug_layer_tap", "ivit_debug_weight_fp8", "ivit_ln_fold_calibrate",
     "ivit_forward_host_async", "ivit_host_wait", "ivit_comm_unique_id", "ivit_comm_init", "ivit_allgather_cls",
-    "ivit_forward_device_packed", "ivit_shard_layout", "ivit_allgather_rows", "ivit_layer_with_attn", "ivit_layer_with_attn_host",
+    "ivit_forward_device_packed", "ivit_shard_layout", "ivit_allgather_rows", "ivit_layer_with_attn", "ivit_layer_with_attn_host", "ivit_fused_mlp", "ivit_split_set",
 )
 
 
@@ -39,7 +39,7 @@ class IvitConfigC(ctypes.Structure):
                 ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PRECISIONS = {"bf16": 0, "fp8": 1, "f16": 2, "f16x": 3, "fp8m": 4}
 
 
@@ -78,6 +78,10 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.ivit_weights_ready.argtypes = [c_p]
         lib.ivit_ln_fold.argtypes = [c_p, c_i]
         lib.ivit_ln_fold.restype = c_i
+        lib.ivit_fused_mlp.argtypes = [c_p, c_i]
+        lib.ivit_fused_mlp.restype = c_i
+        lib.ivit_split_set.argtypes = [c_p]
+        lib.ivit_split_set.restype = c_i
         lib.ivit_forward_host.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64]
         lib.ivit_forward_host_chained.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
         lib.ivit_forward_host_async.argtypes = [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
@@ -456,6 +460,11 @@ class Engine:
         (include/ivit.h: ivit_ln_fold)?  What the rounding-aware oracle has to mirror for that call."""
         return bool(self.lib.ivit_ln_fold(self._h, int(batch)))
 
+    def fused_mlp_for(self, batch: int) -> int:
+        """0: the MLP of a forward of `batch` images runs as two GEMM launches; else the form of the fused MLP kernel (include/ivit.h: ivit_fused_mlp).
+        Either way the same bytes come out: the oracle's rounding-aware mode needs no switch for it."""
+        return int(self.lib.ivit_fused_mlp(self._h, int(batch)))
+
     def calibrate_ln_fold(self, images: torch.Tensor, threshold: float = 0.5) -> float:
         """Guard of the LayerNorm fold for THIS weight set (include/ivit.h: ivit_ln_fold_calibrate): one forward of
         `images` ([B,3,S,S] in [0,1]) with LayerNorm kernels, returns max |mean| / std over all LayerNorm input rows;
@@ -534,12 +543,17 @@ class Engine:
     def split_gemms(self) -> frozenset:
         """The GEMMs this engine multiplies as hi + lo pairs of f16 values (include/ivit.h: IVIT_PRECISION_F16 / F16X) - what the
         oracle's rounding-aware mode mirrors (oracle/vit_oracle.py: SPLIT_GEMMS)."""
-        if self.precision == "f16x":
-            extra = {"proj"} if os.environ.get("IVIT_F16X_PROJ", "1") != "0" else set()
-            return frozenset({"patch", "head", "mlp1w", "mlp2w"} | extra)
-        if self.precision == "f16" and os.environ.get("IVIT_F16_SPLIT_PATCH_HEAD", "1") != "0":
-            return frozenset({"patch", "head"})
-        return frozenset()
+        bits = int(self.lib.ivit_split_set(self._h))   # (the engine decides - per model and from its IVIT_F16X_* knobs; include/ivit.h: ivit_split_set)
+        names = set()
+        if bits & 1:
+            names |= {"patch", "head"}
+        if bits & 2:
+            names.add("proj")
+        if bits & 4:
+            names.add("mlp1w")
+        if bits & 8:
+            names.add("mlp2w")
+        return frozenset(names)
 
     TAPS = {"h1": 1, "qkv": 2, "att": 3, "proj": 4, "h2": 5, "u": 6, "out": 7}
 

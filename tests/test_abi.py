@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     exported = set(re.findall(r"\bT (ivit_[a-z_0-9]+)", out))
     assert set(header_symbols()) <= exported
     lib = engine.load_library()
-    assert lib.ivit_abi_version() == engine.ABI_VERSION == 9
+    assert lib.ivit_abi_version() == engine.ABI_VERSION == 10
     assert b"gfx950" in lib.ivit_build_info()
 
 

@@ -450,7 +450,7 @@ def test_config2_vit_b16_batch64_f16x_as_dispatched():
     """IVIT_PRECISION_F16X at the bench batch: the out-projection on hi + lo pairs of both operands, MLP up / down on hi + lo weight
     pairs - every step gated on the engine's own operand bytes (the attention tap carries [hi | lo])."""
     run_config("vit_b_16", 64, "f16x",
-               {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs", "mlp": "ivit_mlp_fused_f16x_d768"},
+               {"qkv": "ivit_gemm_f16_256x256x64_stag_lf", "proj": "ivit_gemm_f16_160x128x64_rs", "mlp": "ivit_mlp_fused_f16x1_d768"},
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
 

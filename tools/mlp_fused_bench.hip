@@ -16,7 +16,7 @@ using namespace ivit;
 template <int DBG>
 __global__ __launch_bounds__(512, 2) void mlpf_study_bf16(MlpFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    mlp_fused_body<12, 1, OpBf16, DBG>(p, smem);
+    mlp_fused_body<12, 1, 1, OpBf16, DBG>(p, smem);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
