@@ -28,7 +28,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) extended with
                    downloaded every step (never `value`);
   "parity"       - max|gpu - ref| / max|ref| against the oracle in the same run, per node class;
   "tolerance_mode" - (bf16 runs on one GPU) the same workload on IVIT_PRECISION_F16X, the precision that is inside
-                   north_star's 1e-3 of the CPU f32 forward: images/s, GEMM-class fraction, logits vs the plain f32 oracle.
+                   north_star's 1e-3 of the CPU f32 forward: images/s, GEMM-class fraction, logits vs the plain f32 oracle;
+  "layernorm_kernels" - (one GPU, when the LayerNorm fold is on) the same workload with IVIT_FOLD_LN=0: LayerNorm as kernels and the
+                   MLP as two GEMM launches - the rate a checkpoint gets whose statistics trip the fold's guard.
 """
 from __future__ import annotations
 
@@ -64,6 +66,7 @@ def parse():
     ap.add_argument("--precision", default=None, choices=["bf16", "f16", "f16x", "fp8", "fp8m"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tolerance-mode", action="store_true", help="skip the f16x sub-record of a bf16 run")
+    ap.add_argument("--no-layernorm-leg", action="store_true", help="skip the IVIT_FOLD_LN=0 sub-record")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline: total seconds over its three samples")
     args = ap.parse_args()
     model, batch, prec = CONFIGS[args.config or 2]
@@ -232,10 +235,56 @@ def tolerance_mode_record(cfg, sd, x, B, steps, warmup, dev, local_rank, precisi
         return {"precision": precision, "split_gemms": sorted(eng.split_gemms), "value": round(B * steps / el, 1), "unit": "images/s",
                 "ms_per_step": round(el * 1e3 / steps, 4), "steps": steps,
                 "gemm_useful_tflops": round(tf, 1), "gemm_frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4),
-                "gemm_kernels": sorted({k.split(":", 1)[1] for k in kern if k.split(":", 1)[1].startswith("ivit_gemm")}),
+                "gemm_kernels": sorted({k.split(":", 1)[1] for k in kern if _is_gemm_class_kernel(k.split(":", 1)[1])}),
                 "logits_vs_plain_f32_oracle": err, "images": nimg, "bound": 1e-3, "ok": bool(err <= 1e-3),
-                "what": "f16 MFMA operands (the bf16 rate on gfx950); MLP up / down weights as hi + lo pairs of f16 values (two passes, one f32 "
-                        "accumulator), patch embedding and head on pairs of both operands; useful FLOPs only in the TFLOP/s figure"}
+                "what": "f16 MFMA operands (the bf16 rate on gfx950); hi + lo pairs of f16 values (two or three passes, one f32 accumulator) in the "
+                        "GEMMs `split_gemms` names (a trailing w: the weight only; ivit_split_set) - the up weight of the MLP, both operands of the "
+                        "out-projection, patch embedding and head; useful FLOPs only in the TFLOP/s figure"}
+    finally:
+        eng.close()
+
+
+def _is_gemm_class_kernel(name: str) -> bool:
+    return name.startswith("ivit_gemm") or name.startswith("ivit_mlp_fused")
+
+
+def layernorm_kernels_record(cfg, sd, x, B, steps, warmup, dev, local_rank, precision):
+    """The same workload with the LayerNorm fold switched off (IVIT_FOLD_LN=0): LayerNorm as kernels, the MLP as two GEMM launches.  The
+    fold is guarded per call by the row statistics (include/ivit.h: ivit_ln_fold) - a checkpoint whose activations trip the guard runs
+    THIS path, so its rate is reported beside the headline."""
+    from interactive_vit_amd.engine import Engine
+    old = os.environ.get("IVIT_FOLD_LN")
+    os.environ["IVIT_FOLD_LN"] = "0"
+    try:
+        eng = Engine(cfg, sd, device=local_rank, max_batch=B, precision=precision)
+    finally:
+        if old is None:
+            os.environ.pop("IVIT_FOLD_LN", None)
+        else:
+            os.environ["IVIT_FOLD_LN"] = old
+    try:
+        assert not eng.ln_fold_for(B)
+        ns = len(eng.stages)
+        stream = torch.cuda.current_stream(dev)
+        logits = torch.empty((B, cfg.classes), dtype=torch.float32, device=dev)
+        clsf = torch.empty((B, cfg.dim), dtype=torch.float32, device=dev)
+        for _ in range(warmup):
+            eng.forward_into(x, logits, clsf, B, 0, ns, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.forward_into(x, logits, clsf, B, 0, ns, stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        eng.profile(True)
+        eng.profile_reset()
+        for _ in range(steps):
+            eng.forward_into(x, logits, clsf, B, 0, ns, stream.cuda_stream)
+        cls = eng.profile_read()
+        eng.profile(False)
+        return {"value": round(B * steps / el, 1), "unit": "images/s", "ms_per_step": round(el * 1e3 / steps, 4), "steps": steps, "precision": precision,
+                "per_class_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in cls.items()},
+                "what": "IVIT_FOLD_LN=0: LayerNorm kernels + two-launch MLP; the path of a call whose row statistics trip the fold's guard"}
     finally:
         eng.close()
 
@@ -497,10 +546,10 @@ def main():
                 gbs = rec["bytes"] / (rec["ms"] * 1e-3) / 1e9
                 ent.update({"bound": "hbm", "achieved_gbs": round(gbs, 1), "frac": round(gbs / 8000.0, 4)})
             per_kernel.append(ent)
-        gemm_names = sorted({k.split(":", 1)[1] for k, r in kernels.items() if k.split(":", 1)[1].startswith("ivit_gemm")})
+        gemm_names = sorted({k.split(":", 1)[1] for k, r in kernels.items() if _is_gemm_class_kernel(k.split(":", 1)[1])})
         roofline = {"bound": "mfma",
                     "kernel": ", ".join(gemm_names) + " (all GEMM launches of the step; tile picked per shape"
-                              + ("; _lf / _rs = the LayerNorm-fold epilogues, which carry the LayerNorm work" if (args.precision not in ("fp8", "fp8m") and eng.ln_fold_for(B)) else "") + ")",
+                              + ("; _lf / _rs = the LayerNorm-fold epilogues, which carry the LayerNorm work; ivit_mlp_fused = LN2 -> up -> GELU -> down -> residual in one launch" if (args.precision not in ("fp8", "fp8m") and eng.ln_fold_for(B)) else "") + ")",
                     "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_per_step": g["launches"] // args.steps, "avg_launch_us": round(avg_us, 2),
@@ -578,6 +627,14 @@ def main():
         except Exception as ex:   # never takes the headline down; the record says what happened
             tolerance = {"precision": "f16x", "error": repr(ex), "ok": False}
 
+    ln_leg = None
+    if rank == 0 and world == 1 and folded and not args.no_layernorm_leg:
+        eng.close()
+        try:
+            ln_leg = layernorm_kernels_record(cfg, sd, x, B, args.steps, args.warmup, dev, local_rank, args.precision)
+        except Exception as ex:
+            ln_leg = {"error": repr(ex)}
+
     if use_dist:
         dist.barrier()
     if rank == 0:
@@ -597,7 +654,7 @@ def main():
                        "gflop_per_image": round(flops_img / 1e9, 3), "parallelism": f"dp{world}",
                        "weights": "random init N(0,0.02^2) seed 0",
                        "layernorm": "folded into the consuming GEMMs" if folded else "kernel"},
-            "roofline": roofline, "cpu_baseline": cpu, "tolerance_mode": tolerance, "step_ms": step_ms, "pcie_inclusive": pcie, "parity": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "tolerance_mode": tolerance, "layernorm_kernels": ln_leg, "step_ms": step_ms, "pcie_inclusive": pcie, "parity": parity,
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
