@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--model", default=None)
     ap.add_argument("--batch-per-gpu", type=int, default=None)
     ap.add_argument("--precision", default=None, choices=["bf16", "f16", "f16x", "fp8", "fp8m"])
+    ap.add_argument("--weights", default="spec", choices=["spec", "realistic"],
+                    help="spec: random init N(0, 0.02^2) seed 0 (the headline); realistic: the same shapes with real-checkpoint statistics (weights.realistic_statistics_weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tolerance-mode", action="store_true", help="skip the f16x sub-record of a bf16 run")
     ap.add_argument("--no-layernorm-leg", action="store_true", help="skip the IVIT_FOLD_LN=0 sub-record")
@@ -207,6 +209,8 @@ def tolerance_mode_record(cfg, sd, x, B, steps, warmup, dev, local_rank, precisi
     from oracle import vit_oracle as vo
     eng = Engine(cfg, sd, device=local_rank, max_batch=B, precision=precision)
     try:
+        if eng.ln_fold:
+            eng.calibrate_ln_fold(x[:min(4, B)])     # as the plugin backend does (models/vit.py: HipBackend), outside the timed region
         ns = len(eng.stages)
         stream = torch.cuda.current_stream(dev)
         logits = torch.empty((B, cfg.classes), dtype=torch.float32, device=dev)
@@ -375,8 +379,13 @@ def main():
     cfg = VARIANTS[args.model]
     B = args.batch_per_gpu
     total = B * world
-    sd = init_weights(cfg, seed=0, mode="spec")                 # replicated weights, seed 0
+    if args.weights == "realistic":
+        from interactive_vit_amd.weights import realistic_statistics_weights
+        sd = realistic_statistics_weights(cfg, seed=21)
+    else:
+        sd = init_weights(cfg, seed=0, mode="spec")             # replicated weights, seed 0
     eng = Engine(cfg, sd, device=local_rank, max_batch=B, precision=args.precision)
+    fold_ratio = None
     peak = PEAK_FP8_TFLOPS if args.precision == "fp8" else PEAK_BF16_TFLOPS
     if args.precision == "fp8m":   # MLP up / down on the fp8 MFMA, the rest of the GEMM class on the bf16 one: the time-weighted (harmonic) blend
         mlp = 2.0 * cfg.mlp / (4.0 * cfg.dim + 2.0 * cfg.mlp)      # share of the encoder GEMM FLOPs that is MLP up + down
@@ -386,6 +395,11 @@ def main():
     x = synthetic_images(B, cfg, seed=1234 + rank, device=f"cuda:{local_rank}")   # generated on device
     if args.precision in ("fp8", "fp8m"):
         eng.calibrate_fp8(x)        # static activation scales + weight quantisation, outside the timed region
+    elif eng.ln_fold:
+        # what the plugin backend does for whatever weights it is handed (models/vit.py: HipBackend): the LayerNorm-fold calibration - centre vectors of
+        # the 16-bit copies + the guard - on sample images, outside the timed region.  The timed forward then runs the kernels a deployment runs.
+        # (every rank calibrates on rank 0's first images: an image's result must not depend on the shard it lands in)
+        fold_ratio = eng.calibrate_ln_fold(synthetic_images(min(4, B), cfg, seed=1234, device=f"cuda:{local_rank}"))
     # the ONE collective of the path is issued by the engine itself through RCCL (include/ivit.h: ivit_allgather_cls); torch's
     # process group only carries the communicator id, the barriers and the max-over-ranks of the timing (IVIT_GATHER=torch
     # routes the all-gather through torch.distributed instead: the round-1 path, kept for A/B)
@@ -565,6 +579,7 @@ def main():
     if rank == 0:
         from oracle import vit_oracle as vo
         vo.LN_FOLD = eng.ln_fold_for(B)  # the rounding-aware oracle mirrors the rounding points of THIS batch size
+        vo.LN_CENTRE = eng.ln_centres() if eng.ln_fold else None
         vo.OPERAND_DTYPE = eng.operand_dtype
         vo.SPLIT_GEMMS = eng.split_gemms
         # The bounds this run is held to (exit code 3 when one is violated).  Against the PLAIN f32 forward - what the reference's sub(x)
@@ -635,6 +650,7 @@ def main():
         except Exception as ex:
             ln_leg = {"error": repr(ex)}
 
+    eng_ratio_plain = getattr(eng, "ln_fold_ratio_plain", 0.0)
     if use_dist:
         dist.barrier()
     if rank == 0:
@@ -652,8 +668,9 @@ def main():
                        "collective_overlap": ("async on RCCL's stream behind the next step's compute, drained inside the timed region" if overlap else "in line") if use_dist else None,
                        "batch_per_gpu": B, "global_batch": total, "tokens": cfg.tokens,
                        "gflop_per_image": round(flops_img / 1e9, 3), "parallelism": f"dp{world}",
-                       "weights": "random init N(0,0.02^2) seed 0",
-                       "layernorm": "folded into the consuming GEMMs" if folded else "kernel"},
+                       "weights": "random init N(0,0.02^2) seed 0" if args.weights == "spec" else "random, real-checkpoint statistics (weights.realistic_statistics_weights seed 21)",
+                       "layernorm": ("folded into the consuming GEMMs" + (f"; 16-bit copies centred about calibrated per-channel means, guard statistic {fold_ratio:.3f} "
+                                     f"(plain copies {eng_ratio_plain:.3f})" if fold_ratio is not None else "")) if folded else "kernel"},
             "roofline": roofline, "cpu_baseline": cpu, "tolerance_mode": tolerance, "layernorm_kernels": ln_leg, "step_ms": step_ms, "pcie_inclusive": pcie, "parity": parity,
         }
         sys.stdout.flush()

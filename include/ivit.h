@@ -124,15 +124,28 @@ int ivit_fused_mlp(const ivit_engine* e, int batch);
  * weight (by default only where the fused MLP kernel cannot run - dim other than 512 / 768; IVIT_F16X_MLP2=0 / 1 overrides). */
 int ivit_split_set(const ivit_engine* e);
 
-/* Guard of the LayerNorm fold for a weight set.  The folded GEMM multiplies the UNCENTRED 16-bit copy of the residual
- * stream, so its operand-rounding noise is sqrt(1 + (mean/std)^2) times the unfolded form's, mean / std taken per
- * token row of the LayerNorm input - small for the seeded weights of the tests, not guaranteed for a user-supplied
- * checkpoint (reference plugins load whatever state dict they are given, static/models/vgg16.py:12-14).  This entry
- * runs one forward of `batch` sample images (`in`: device f32 [B,3,S,S] in [0,1]) with LayerNorm kernels, records
- * max |mean| / std over every LayerNorm input row of every layer into *max_ratio (optional), and keeps the fold for
- * this engine only if that maximum is <= threshold (0.5: at most 12 % more rounding noise); otherwise every later call
- * uses the LayerNorm kernels (ivit_ln_fold then answers 0).  Synchronises `stream`. */
+/* Calibration and guard of the LayerNorm fold for a weight set.  The folded GEMM multiplies a 16-bit copy of the residual-stream rows that is not
+ * centred per row, so its operand-rounding noise is rms(copy) / std(x) times the unfolded form's (which rounds (x - mean) rstd) - a factor
+ * sqrt(1 + (mean/std)^2) for the plain copy rn16(x): small for the seeded weights of the tests, not guaranteed for a user-supplied checkpoint
+ * (reference plugins load whatever state dict they are given, static/models/vgg16.py:12-14), whose rows carry channel-constant offsets and outlier
+ * channels.  Those are constant across rows, so this entry (round 5) removes them before the rounding: it runs one forward of `batch` sample images
+ * (`in`: device f32 [B,3,S,S] in [0,1]) with LayerNorm kernels, takes at every LayerNorm input of every layer the per-channel mean over the rows as
+ * that input's CENTRE vector m, and from then on the engine's copies are rn16(x - m) and the folded GEMMs add d = W' m back in their epilogues:
+ *     LN(x) W^T + b = rstd (rn16(x - m) W'^T + d - mean s) + c        (statistics mean / rstd are those of x itself; m = 0 reproduces rounds 3-4).
+ * The guard statistic is the noise factor as sqrt(factor^2 - 1) - for the plain copy |mean| / std - max over the rows of a LayerNorm input.  A
+ * population mean does not suit every row (a class-token row that lacks the patch rows' common offset gets WORSE when that offset is subtracted), so
+ * each of the 2 * layers inputs keeps its vector only where the centred copies' statistic is below the plain copies' - otherwise that input stays
+ * on the plain copy (vector zero).  *max_ratio (optional) receives the maximum over the inputs of the statistic of the copy each one uses, and the fold
+ * is kept for this engine only if it is <= threshold (0.5: at most 12 % more rounding noise than the LayerNorm kernels); otherwise every later call
+ * uses the LayerNorm kernels (ivit_ln_fold then answers 0).
+ * IVIT_FOLD_CENTRE=0 in the environment at ivit_create keeps the plain copy (guard on |mean| / std, as before).  ivit_set_weight drops the vectors
+ * (plain copy again until the next calibration).  Synchronises `stream`. */
 int ivit_ln_fold_calibrate(ivit_engine* e, int batch, const void* in, float threshold, float* max_ratio, void* stream);
+
+/* The centre vectors of the last calibration, for a checker that mirrors the engine's rounding points: out (optional, room for 2 * layers * dim
+ * floats) receives m of LN1 of layer 0, LN2 of layer 0, LN1 of layer 1, ... (zeros when the copies are not centred); *centred (optional) says whether
+ * they are in use, *plain_ratio (optional) receives the guard statistic of the PLAIN copy at that calibration (what rounds 3-4 guarded on). */
+int ivit_ln_fold_centres(ivit_engine* e, float* out, int64_t capacity, int* centred, float* plain_ratio);
 
 /* Replaces: Model.compute -> sub(x)  (reference main/context.py:79-88) for a run of nodes.
  * Host-buffer form (interactive path: the request tensors are CPU f32, main/message.py:58):

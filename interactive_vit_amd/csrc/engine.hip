@@ -4,7 +4,9 @@
 #include "../../include/ivit.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -169,6 +171,7 @@ struct LayerWeights {
     // LayerNorm folded into the GEMM that consumes it: W' = W . diag(gamma) (bf16), s = row sums of W', c = W beta + b
     Matrix wf_in, wf_1;
     float *s_in = nullptr, *c_in = nullptr, *s_1 = nullptr, *c_1 = nullptr;
+    float *d_in = nullptr, *d_1 = nullptr;   // centred operand rows (kernels.h: GemmParams::ln_d): d = W' . centre of the LayerNorm input, written by ivit_ln_fold_calibrate
     bf16_t* wp_mlp = nullptr;   // fused MLP (kernels_mlp.hip): wf_1 and w2 in the kernel's fragment-native stream order
     float s_h1 = 1.f, s_att = 1.f, s_h2 = 1.f, s_u = 1.f;   // static activation scales (calibrated)
 };
@@ -237,6 +240,14 @@ struct ivit_engine {
     uint64_t stats_token = 0; int stats_batch = 0;   // resident_token of the host-call output whose LayerNorm statistics pairs / 16-bit copy are in the workspace
     bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
     bool fused_mlp = false;         // LN2 -> MLP up -> GELU -> MLP down -> residual in ONE launch where the shape allows (IVIT_FUSED_MLP=0 switches it off)
+    // Centred operand copy (round 5): one calibrated per-channel vector per LayerNorm input - site 2 i = LN1 of layer i, 2 i + 1 = LN2 - subtracted before the
+    // 16-bit rounding of the rows the folded GEMMs multiply (kernels.h: GemmParams::ln_centre / ln_d).  Zero and unused until ivit_ln_fold_calibrate has run.
+    float* centre = nullptr;        // [2 L][D]
+    bool centre_on = true;          // IVIT_FOLD_CENTRE=0: calibrate the guard on the plain copy, as rounds 3-4 did
+    bool centred = false;           // some site's vector is in use
+    std::vector<char> site_on;      // [2 L]: this site's copies are centred (the calibration keeps a vector only where it lowers the site's guard statistic:
+                                    // rows that differ from the population - a class-token row without the patches' common offset - get WORSE when a population mean is subtracted)
+    float ratio_plain = 0.f;        // the guard statistic of the plain copy at the last calibration (ivit_ln_fold_centres)
     bool fold_blocked = false;      // ivit_ln_fold_calibrate found rows with |mean| / std above its threshold: keep the LayerNorm kernels
     float* ratio_dev = nullptr;     // calibration scratch: max |mean| / std seen (non-null only while calibrating)
     float* ratio_scratch = nullptr; // its device word, allocated once at ivit_create
@@ -401,6 +412,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         const char* fl = getenv("IVIT_FOLD_LN");
         e->fold_ln = !(fl && atoi(fl) == 0) && !precision_is_fp8(cfg->precision) && cfg->dim <= 64 * GEMM_LN_SLOTS;
         e->fold_always = fl && atoi(fl) == 2;
+        const char* fc = getenv("IVIT_FOLD_CENTRE");
+        e->centre_on = !(fc && atoi(fc) == 0);
         const char* fm = getenv("IVIT_FUSED_MLP");
         e->fused_mlp = e->fold_ln && !(fm && atoi(fm) == 0) && mlp_fused_supported(1, cfg->dim, cfg->mlp, e->f16, mlp_split_mode(e));
         if (e->split < 1 || e->split > ivit_engine::MAX_SPLIT) e->split = 1;
@@ -432,6 +445,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         if (e->fold_ln) {
             chk(alloc_matrix(e, &lw.wf_in, 3 * D, D)); chk(alloc_vec(e, &lw.s_in, 3 * D)); chk(alloc_vec(e, &lw.c_in, 3 * D));
             chk(alloc_matrix_split(e, &lw.wf_1, Mlp, D, e->f16x ? 1 : 0)); chk(alloc_vec(e, &lw.s_1, Mlp)); chk(alloc_vec(e, &lw.c_1, Mlp));
+            chk(alloc_vec(e, &lw.d_in, 3 * D)); chk(alloc_vec(e, &lw.d_1, Mlp));
             if (e->fused_mlp) chk(dev_alloc(e, (void**)&lw.wp_mlp, mlp_fused_packed_bytes(D, Mlp, mlp_split_mode(e)), true));
         }
         if (rc) break;
@@ -463,7 +477,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         for (auto& lw : e->layers) { alloc8(&lw.q_in, 3 * D, D); alloc8(&lw.q_out, D, D); alloc8(&lw.q1, Mlp, D); alloc8(&lw.q2, D, Mlp); }
     }
     chk(alloc_vec(e, &e->clsf, (int64_t)B * D));
-    chk(alloc_vec(e, &e->ratio_scratch, 4));
+    chk(alloc_vec(e, &e->ratio_scratch, 4 * (int64_t)std::max(1, cfg->layers) + 4));   // (plain, centred) guard statistics per LayerNorm input
+    if (e->fold_ln) chk(alloc_vec(e, &e->centre, (int64_t)2 * std::max(1, cfg->layers) * D));
     int64_t per_img = 0;
     for (int s = 0; s < 6 + cfg->layers; ++s)
         for (int w = 0; w < 2; ++w) per_img = std::max(per_img, shape_elems(cfg, s, w));
@@ -585,6 +600,7 @@ extern "C" int ivit_set_weight(ivit_engine* e, const char* name, const float* ho
     e->fp8_ready = false;          // quantised copies are rebuilt by the next ivit_fp8_calibrate
     e->weights_complete = false;   // re-evaluated lazily by the next forward / ivit_weights_ready
     e->fold_ready = false;         // ... which also rebuilds the LayerNorm-folded matrices
+    e->centred = false;            // the centre vectors and their d = W' . centre belong to the old weights: plain copy until the next ivit_ln_fold_calibrate
     return 0;
 }
 
@@ -644,7 +660,13 @@ struct LnFold {
     const float2* stats = nullptr;
     bf16_t* xb = nullptr;
     const float* s = nullptr;
+    const float* centre = nullptr;   // EPI_BIAS_RESID_STATS / ROWADD_STATS: xb = rn16(rows - centre)
+    const float* d = nullptr;        // EPI_LNFOLD_*: W' . centre of the operand rows
 };
+// centre vector of LayerNorm input `site` (2 i: LN1 of layer i, 2 i + 1: LN2), or nullptr where the copy is not centred (no calibration yet / past the last layer)
+static const float* site_centre(const ivit_engine* e, int site) {
+    return (e->centred && site >= 0 && site < (int)e->site_on.size() && e->site_on[site]) ? e->centre + (size_t)site * e->D : nullptr;
+}
 
 static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, const Matrix& W, int M, const float* bias,
                     int epi, void* out, int ldo, const float* resid = nullptr, int ldr = 0, const float* rowadd = nullptr,
@@ -653,7 +675,7 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
     p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld; p.f16 = e->f16; p.a_wrap = W.a_wrap; p.a_shift = W.a_shift;
     p.bias = bias; p.epi = epi; p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr;
     p.rowadd = rowadd; p.ldra = ldra; p.grp_in = grp_in; p.grp_out = grp_out; p.grp_off = grp_off;
-    if (lf) { p.ln_part = lf->part; p.ln_stats = lf->stats; p.xb = lf->xb; p.ldxb = e->D; p.ln_s = lf->s; p.ln_eps = e->cfg.ln_eps; p.ln_dim = e->D; }
+    if (lf) { p.ln_part = lf->part; p.ln_stats = lf->stats; p.xb = lf->xb; p.ldxb = e->D; p.ln_s = lf->s; p.ln_eps = e->cfg.ln_eps; p.ln_dim = e->D; p.ln_centre = lf->centre; p.ln_d = lf->d; }
     const bool bf_out = (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16 || epi == EPI_LNFOLD_BF16 || epi == EPI_LNFOLD_GELU_BF16);
     const bool resid_in = (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_RESID_STATS);
     const bool stats_out = (epi == EPI_BIAS_RESID_STATS || epi == EPI_BIAS_ROWADD_STATS);
@@ -791,12 +813,15 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
     if (!xo) xo = w.x;
     if (e->ratio_on) {
         // LayerNorm-fold calibration: the unfolded path below, with the |mean| / std of both LayerNorm inputs recorded
-        HIP_TRY(launch_row_mean_ratio(xi, D, M, D, e->cfg.ln_eps, e->ratio_dev, st));
+        // (and, where the copy is centred, the column means of both inputs first: the centre vectors the statistic is then taken about)
+        if (e->centre_on) HIP_TRY(launch_col_means(xi, D, M, D, e->centre + (size_t)(2 * li) * D, st));
+        HIP_TRY(launch_row_mean_ratio(xi, D, M, D, e->cfg.ln_eps, e->centre_on ? e->centre + (size_t)(2 * li) * D : nullptr, e->ratio_dev + 2 * (2 * li), st));
         if (run_layernorm(e, st, xi, 1, M, lw.ln1_g, lw.ln1_b, w.h, nullptr)) return 1;
         if (run_gemm(e, st, w.h, D, lw.w_in, M, lw.b_in, EPI_BIAS_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "qkv")) return 1;
         if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
         if (run_gemm(e, st, w.att, e->ld_att, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_F32, w.x, D, xi, D, nullptr, 0, 0, 0, 0, nullptr, "proj")) return 1;
-        HIP_TRY(launch_row_mean_ratio(w.x, D, M, D, e->cfg.ln_eps, e->ratio_dev, st));
+        if (e->centre_on) HIP_TRY(launch_col_means(w.x, D, M, D, e->centre + (size_t)(2 * li + 1) * D, st));
+        HIP_TRY(launch_row_mean_ratio(w.x, D, M, D, e->cfg.ln_eps, e->centre_on ? e->centre + (size_t)(2 * li + 1) * D : nullptr, e->ratio_dev + 2 * (2 * li + 1), st));
         if (run_layernorm(e, st, w.x, 1, M, lw.ln2_g, lw.ln2_b, w.h, nullptr)) return 1;
         if (run_gemm(e, st, w.h, D, lw.w1, M, lw.b1, EPI_BIAS_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, "mlp1")) return 1;
         return run_gemm(e, st, w.u, Mlp, lw.w2, M, lw.b2, EPI_BIAS_RESID_F32, xo, D, w.x, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2");
@@ -810,23 +835,26 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         fold.stats = nullptr;                               // every consumer folds the per-slot pairs, whoever wrote them
         if (!stats_in) {   // nobody left x's pairs and 16-bit copy behind: the kernel that writes what EPI_BIAS_RESID_STATS would have
             ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * D * 6.0);
-            HIP_TRY(launch_row_stats(xi, D, M, D, w.h, D, w.ln_part, st, e->f16));
+            HIP_TRY(launch_row_stats(xi, D, M, D, w.h, D, w.ln_part, st, e->f16, 1, site_centre(e, 2 * li)));
         }
         if (tap == TAP_H1) return 0;
-        fold.s = lw.s_in;
+        fold.s = lw.s_in; fold.d = site_centre(e, 2 * li) ? lw.d_in : nullptr;
         if (run_gemm(e, st, w.h, D, lw.wf_in, M, lw.c_in, EPI_LNFOLD_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "qkv")) return 1;
         if (tap == TAP_QKV) return 0;
         if (run_attention(e, w, st, B, nullptr, 1.0f)) return 1;
         if (tap == TAP_ATT) return 0;
+        fold.centre = site_centre(e, 2 * li + 1);   // the copy of the new rows is LN2's operand
         if (run_gemm(e, st, w.att, e->ld_att, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, xi, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
         if (tap == TAP_PROJ || tap == TAP_H2) return 0;
-        fold.s = lw.s_1;
+        fold.s = lw.s_1; fold.d = site_centre(e, 2 * li + 1) ? lw.d_1 : nullptr;
+        fold.centre = site_centre(e, 2 * li + 2);   // ... and the MLP-down GEMM's copy is LN1's operand of the next layer
         if (tap != TAP_U && fused_mlp_for_rows(e, M)) {
             // MLP up + GELU + MLP down + residual (+ the next layer's statistics pairs and 16-bit copy) in one launch: bit-identical to the two GEMM launches
             // below (tests), the hidden tensor never leaves the CU.  (The TAP_U inspector takes the two-launch path: it wants the hidden tensor itself.)
             MlpFusedParams mp{};
             mp.X = w.h; mp.ldx = D; mp.ln_part_in = w.ln_part; mp.ln_eps = e->cfg.ln_eps; mp.Wp = lw.wp_mlp; mp.c1 = lw.c_1; mp.s1 = lw.s_1; mp.b2 = lw.b2;
             mp.resid = w.x; mp.ldr = D; mp.out = xo; mp.ldo = D; mp.xb = w.h; mp.ldxb = D; mp.ln_part_out = w.ln_part;
+            mp.d1 = fold.d; mp.centre_out = fold.centre;
             mp.M = M; mp.D = D; mp.Mlp = Mlp; mp.f16 = e->f16; mp.split = mlp_split_mode(e); mp.stats_out = stats_out ? 1 : 0;
             const double flops = 4.0 * M * (double)D * Mlp;
             const double bytes = 2.0 * M * D + (double)mlp_fused_packed_bytes(D, Mlp, mlp_split_mode(e)) + 8.0 * M * D + (stats_out ? 2.0 * M * D : 0.0);
@@ -905,7 +933,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         // also leaves the statistics pairs and the 16-bit copy of the token rows (round 3: ivit_row_stats_pairs then only visits the
         // B class rows instead of re-reading the whole stream: 15.7 us -> 2 us at ViT-B/16 B = 64)
         stats_from_patch = end > ST_LAYER0 && e->cfg.layers > 0 && !e->ratio_on && !precision_is_fp8(e->cfg.precision) && fold_for_rows(e, B * N);
-        LnFold pfold; pfold.part = w.ln_part; pfold.xb = w.h;
+        LnFold pfold; pfold.part = w.ln_part; pfold.xb = w.h; pfold.centre = site_centre(e, 0);
         if (run_gemm(e, st, w.patches, e->ld_patch, e->w_patch, B * Np, e->b_patch, stats_from_patch ? EPI_BIAS_ROWADD_STATS : EPI_BIAS_ROWADD_F32,
                      (end == ST_TOKENS + 1) ? out : w.x, D, nullptr, 0, e->pos, D, Np, N, 1, stats_from_patch ? &pfold : nullptr, "patch")) return 1;
         {
@@ -914,7 +942,7 @@ static int forward_one(ivit_engine* e, const Ws& w, int begin, int end, int B, c
         }
         if (stats_from_patch) {
             ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)B * D * 6.0);
-            HIP_TRY(launch_row_stats(w.x, D, B, D, w.h, D, w.ln_part, st, e->f16, N));
+            HIP_TRY(launch_row_stats(w.x, D, B, D, w.h, D, w.ln_part, st, e->f16, N, site_centre(e, 0)));
         }
         if (end == ST_TOKENS + 1) return 0;
         in_x = true;
@@ -1422,32 +1450,75 @@ extern "C" int ivit_ln_fold_calibrate(ivit_engine* e, int batch, const void* in,
     std::lock_guard<std::mutex> lk(e->mu);
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (require_weights(e)) return 1;
+    if (!e->fold_ln) { if (max_ratio) *max_ratio = 0.f; return 0; }   // nothing to guard: this engine runs the LayerNorm kernels anyway
     hipStream_t st = (hipStream_t)stream;
     WsScope ws(e, st);
     if (ws.acquire()) return 1;
     float* dev = e->ratio_scratch;
     int rc = 0;
-    float ratio = 0.f;
+    const int sites = 2 * e->cfg.layers;
+    std::vector<float> stat(2 * (size_t)sites, 0.f);
+    std::vector<char> on(sites, 0);
     do {
-        if (hipMemsetAsync(dev, 0, sizeof(float), st) != hipSuccess) { rc = fail("hipMemsetAsync failed"); break; }
+        if (hipMemsetAsync(dev, 0, stat.size() * sizeof(float), st) != hipSuccess) { rc = fail("hipMemsetAsync failed"); break; }
         const Ws w = ws_slice(e, 0);
         if ((rc = forward_one(e, w, ST_TRANSFORM, ST_LAYER0, batch, (const float*)in, w.x, nullptr, st))) break;   // -> residual stream in w.x
+        // the unfolded path, layer by layer; at both LayerNorm inputs of a layer: the column means of the rows -> that site's centre vector
+        // (IVIT_FOLD_CENTRE=0: none), then the guard statistic of the plain copy and of the copy centred about it (kernels_misc.hip: ivit_row_mean_ratio)
         e->ratio_dev = dev; e->ratio_on = true;
         for (int li = 0; li < e->cfg.layers && !rc; ++li) rc = run_layer(e, w, st, li, batch);
         e->ratio_on = false; e->ratio_dev = nullptr;
         if (rc) break;
-        if (hipMemcpyAsync(&ratio, dev, sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = fail("reading the calibration statistic failed"); break; }
+        if (hipMemcpyAsync(stat.data(), dev, stat.size() * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = fail("reading the calibration statistics failed"); break; }
+        // a site keeps its vector only where that LOWERS its statistic (a non-finite one never compares below); the others go back to the plain copy
+        for (int sidx = 0; sidx < sites && !rc; ++sidx) {
+            on[sidx] = e->centre_on && stat[2 * sidx + 1] < stat[2 * sidx];
+            if (!on[sidx] && hipMemsetAsync(e->centre + (size_t)sidx * e->D, 0, (size_t)e->D * sizeof(float), st) != hipSuccess) rc = fail("hipMemsetAsync failed");
+        }
+        // d = W' . centre for the folded GEMM behind every centred site, over the 16-bit matrices as they are multiplied
+        for (int li = 0; li < e->cfg.layers && !rc; ++li) {
+            LayerWeights& lw = e->layers[li];
+            if (on[2 * li] && launch_centre_dot(lw.wf_in.p, lw.wf_in.ld, lw.wf_in.rows, lw.wf_in.cols, 0, e->centre + (size_t)(2 * li) * e->D, lw.d_in, st, e->f16) != hipSuccess) rc = fail("launch_centre_dot failed");
+            if (!rc && on[2 * li + 1] && launch_centre_dot(lw.wf_1.p, lw.wf_1.ld, lw.wf_1.rows, lw.wf_1.cols, lw.wf_1.split ? 1 : 0, e->centre + (size_t)(2 * li + 1) * e->D, lw.d_1, st, e->f16) != hipSuccess) rc = fail("launch_centre_dot failed");
+        }
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail("hipStreamSynchronize failed");
     } while (0);
     e->ratio_on = false; e->ratio_dev = nullptr;
     if (ws.release()) return 1;
     if (rc) return 1;
-    const bool blocked = !(ratio <= threshold);   // a non-finite statistic (NaN wins the unsigned atomicMax of the kernel) blocks the fold too
-    if (blocked != e->fold_blocked) {   // captured launch sequences embed the old choice
-        for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-        e->graphs.clear();
+    float guard = 0.f, plain = 0.f;
+    bool bad = false, any = false;
+    for (int sidx = 0; sidx < sites; ++sidx) {
+        const float eff = on[sidx] ? stat[2 * sidx + 1] : stat[2 * sidx];
+        if (!(eff == eff) || !(stat[2 * sidx] == stat[2 * sidx])) bad = true;   // NaN: a non-finite row blocks the fold
+        guard = std::max(guard, eff);
+        plain = std::max(plain, stat[2 * sidx]);
+        any = any || on[sidx];
     }
+    const bool blocked = bad || !(guard <= threshold);
+    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);   // captured launch sequences embed the old choice and the old vectors' use
+    e->graphs.clear();
     e->fold_blocked = blocked;
-    if (max_ratio) *max_ratio = ratio;
+    e->site_on = on;
+    e->centred = any;
+    e->ratio_plain = plain;
+    e->stats_token = 0;   // statistics / copies a host call left behind were taken about the old vectors
+    if (max_ratio) *max_ratio = bad ? std::numeric_limits<float>::quiet_NaN() : guard;
+    return 0;
+}
+
+extern "C" int ivit_ln_fold_centres(ivit_engine* e, float* out, int64_t capacity, int* centred, float* plain_ratio) {
+    if (!e) return fail("ivit_ln_fold_centres: null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int64_t n = (int64_t)2 * e->cfg.layers * e->D;
+    if (centred) *centred = e->centred ? 1 : 0;
+    if (plain_ratio) *plain_ratio = e->ratio_plain;
+    if (out) {
+        if (capacity < n) return fail("ivit_ln_fold_centres: need room for %lld floats", (long long)n);
+        if (e->centred && e->centre) { HIP_TRY(hipMemcpy(out, e->centre, (size_t)n * sizeof(float), hipMemcpyDeviceToHost)); }
+        else std::fill(out, out + n, 0.f);
+    }
     return 0;
 }
 

@@ -122,10 +122,7 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     }
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_acc_init<T, EK>(p, acc, n0 + wc * 64, fq);
 
     float2* tile_stats = reinterpret_cast<float2*>(smem + T::LDS_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
 #if !IVIT_LN_STATS_AFTER_DMA

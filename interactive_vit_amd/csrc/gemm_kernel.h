@@ -435,12 +435,16 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
             for (int r = 0; r < 4; ++r) { acc[i][j][r] = v[r]; if (INTERIOR || n + r < p.N) sum += v[r]; }
             float* o = reinterpret_cast<float*>(p.out) + (size_t)mr * p.ldo + n;
             bf16_t* ob = p.xb + (size_t)mr * p.ldxb + n;
+            // the 16-bit copy is rn16(x - centre[n]) (GemmParams::ln_centre; the statistics and the f32 stream are those of x itself).  Re-read per fragment
+            // row from L1 rather than held across the rows: 16 more live registers spilled in the edge workgroup of the fused MLP kernel
+            float ct[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.ln_centre) for (int r = 0; r < 4; ++r) if (INTERIOR || n + r < p.N) ct[r] = p.ln_centre[n + r];
             if (INTERIOR || (row_ok && n + 3 < p.N)) {
                 *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                u32x2 pk = {OP::pack2(v[0], v[1]), OP::pack2(v[2], v[3])};
+                u32x2 pk = {OP::pack2(v[0] - ct[0], v[1] - ct[1]), OP::pack2(v[2] - ct[2], v[3] - ct[3])};
                 *reinterpret_cast<u32x2*>(ob) = pk;
             } else if (row_ok) {
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) { o[r] = v[r]; ob[r] = OP::from_f32(v[r]); }
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) { o[r] = v[r]; ob[r] = OP::from_f32(v[r] - ct[r]); }
             }
         }
         sum += __shfl_xor(sum, 16, 64);
@@ -474,6 +478,9 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats(const GemmParams& p, f
 // tile at once at the start of the epilogue changed nothing), while the loops before it barely touch HBM.  With the second workgroup of
 // every CU fetching its residual rows up front (its first K-tile wait also waits for them: vmcnt is in order - it starts ~4 us late,
 // while the first workgroup has the CU's operand path to itself) the two phases of the two workgroups interleave.
+#ifndef IVIT_RS_COPY_LAST
+#define IVIT_RS_COPY_LAST 0   // study builds: 1 = the 16-bit copy always after the statistics (where the centred copy has to be)
+#endif
 #ifndef IVIT_RS_PREFETCH_ROWS
 #define IVIT_RS_PREFETCH_ROWS 8   // fragment rows held across the K loop (16 registers each; capped at the tile's FM): all five of the 160 x 128 tile = 212 registers, no scratch
 #endif
@@ -500,6 +507,7 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats_interior(const GemmPar
     float4 bias4[T::FN];
 #pragma unroll
     for (int j = 0; j < T::FN; ++j) bias4[j] = *reinterpret_cast<const float4*>(p.bias + n_base + j * 16 + fq * 4);
+    const bool centred = p.ln_centre != nullptr;   // (wave-uniform) the 16-bit copy is rn16(x - centre[n]); statistics and stream are those of x itself
     int orow[T::FM];
     const float* src[T::FM];
     if (p.grp_in > 0) {   // EPI_BIAS_ROWADD_STATS: GEMM row -> token row of its image, the addend is the table row (position embedding)
@@ -559,13 +567,16 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats_interior(const GemmPar
                 for (int r = 0; r < 4; ++r) { acc[i][j][r] = v[r]; sum += v[r]; }
                 *reinterpret_cast<float4*>(o + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
             }
+            auto store_copy = [&]() {   // 16-bit copy: 16-byte stores (lane rows fq / fq ^ 1 trade quads of a fragment pair)
 #pragma unroll
-            for (int j = 0; j < T::FN; j += 2) {   // 16-bit copy: 16-byte stores (lane rows fq / fq ^ 1 trade quads of a fragment pair)
-                const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(acc[i][j][0], acc[i][j][1]), OP::pack2(acc[i][j + 1][0], acc[i][j + 1][1]), false, false);
-                const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(acc[i][j][2], acc[i][j][3]), OP::pack2(acc[i][j + 1][2], acc[i][j + 1][3]), false, false);
-                u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
-                *reinterpret_cast<u32x4*>(ob + (j + (fq & 1)) * 16 + (fq & ~1) * 4) = pk;
-            }
+                for (int j = 0; j < T::FN; j += 2) {
+                    const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(acc[i][j][0], acc[i][j][1]), OP::pack2(acc[i][j + 1][0], acc[i][j + 1][1]), false, false);
+                    const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(acc[i][j][2], acc[i][j][3]), OP::pack2(acc[i][j + 1][2], acc[i][j + 1][3]), false, false);
+                    u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
+                    *reinterpret_cast<u32x4*>(ob + (j + (fq & 1)) * 16 + (fq & ~1) * 4) = pk;
+                }
+            };
+            if (!centred && !IVIT_RS_COPY_LAST) store_copy();   // plain copy: beside the f32 stores, as rounds 3-4
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float lmean = sum / 64.0f;
@@ -577,7 +588,35 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats_interior(const GemmPar
             m2 += __shfl_xor(m2, 16, 64);
             m2 += __shfl_xor(m2, 32, 64);
             if (fq == 0) p.ln_part[(size_t)mr * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
+            // 16-bit copy, last: the row's values are dead after the statistics, so a centred copy (rn16(x - centre[n])) subtracts IN PLACE, one column quad at a
+            // time (re-read per fragment row from L1: held across the rows, or subtracted beside live values, the vector spilled in the 168-register tiles)
+            if (centred) {
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) {
+                    const float4 ct = *reinterpret_cast<const float4*>(p.ln_centre + n_base + j * 16 + fq * 4);
+                    acc[i][j][0] -= ct.x; acc[i][j][1] -= ct.y; acc[i][j][2] -= ct.z; acc[i][j][3] -= ct.w;
+                }
+            }
+            if (centred || IVIT_RS_COPY_LAST) store_copy();
         }
+    }
+}
+
+// Accumulators of a tile at the start of its K loop: zero - or, for an EPI_LNFOLD_* GEMM on centred operand rows (GemmParams::ln_d), d[n] in every row of
+// column n, so that the epilogue's acc already holds rn16(x - centre) W'^T + centre W'^T.  (Adding d in the epilogue instead cost 16 more live registers
+// there: 130-320 bytes of scratch in the 168-register and the 256 x 256 kernels.)  The loads are issued ahead of the first operand DMA: its wait covers them.
+template <class T, int EK>
+__device__ __forceinline__ void gemm_acc_init(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int n_base, int fq) {
+#pragma unroll
+    for (int j = 0; j < T::FN; ++j) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (EK == 2 && p.ln_d) {   // (wave-uniform)
+            const int n = n_base + j * 16 + fq * 4;
+            if (n + 3 < p.N) { const float4 t = *reinterpret_cast<const float4*>(p.ln_d + n); d = f32x4{t.x, t.y, t.z, t.w}; }
+            else for (int r = 0; r < 4; ++r) if (n + r < p.N) d[r] = p.ln_d[n + r];
+        }
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i) acc[i][j] = d;
     }
 }
 
@@ -816,10 +855,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     const int n0 = tn * T::BN;
 
     f32x4 acc[T::FM][T::FN];
-#pragma unroll
-    for (int i = 0; i < T::FM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_acc_init<T, EK>(p, acc, n0 + wc * T::FN * 16, (threadIdx.x & 63) >> 4);
 
     // a K-tile is 128 BYTES of every row: 64 bf16 or 128 fp8
     constexpr int ESZ = FP8 ? 1 : 2;
@@ -944,10 +980,7 @@ __device__ __forceinline__ void gemm_body_sb(const GemmParams& p, char* smem) {
     tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn);
     const int m0 = tm * T::BM, n0 = tn * T::BN;
     f32x4 acc[T::FM][T::FN];
-#pragma unroll
-    for (int i = 0; i < T::FM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_acc_init<T, EK>(p, acc, n0 + wc * T::FN * 16, (threadIdx.x & 63) >> 4);
     // a K-tile is 128 BYTES of every row: 64 bf16 / f16 or 128 fp8
     constexpr int ESZ = FP8 ? 1 : 2;
     const size_t lda_b = (size_t)p.lda * ESZ, ldw_b = (size_t)p.ldw * ESZ;
@@ -1030,10 +1063,7 @@ __device__ __forceinline__ void gemm_body_deep(const GemmParams& p, char* smem) 
     const int m0 = tm * T::BM, n0 = tn * T::BN;
 
     f32x4 acc[T::FM][T::FN];
-#pragma unroll
-    for (int i = 0; i < T::FM; ++i)
-#pragma unroll
-        for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_acc_init<T, EK>(p, acc, n0 + wc * T::FN * 16, (threadIdx.x & 63) >> 4);
 
     const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
     const int nt = p.K / GEMM_BK, last = nt - 1;

@@ -50,6 +50,11 @@ struct GemmParams {
     bf16_t* xb; int ldxb;           // EPI_BIAS_RESID_STATS: bf16 copy of the new residual rows
     const float* ln_s;              // EPI_LNFOLD_*: s[n] = sum_k W'[n][k]          (bias = c[n])
     float ln_eps; int ln_dim;       // EPI_LNFOLD_*: LayerNorm epsilon and width (= K of this GEMM)
+    // Centred operand copy (round 5): the 16-bit copy of the rows is rn16(x - centre[n]) with a calibrated per-channel vector (ivit_ln_fold_calibrate), so that
+    // channel-constant offsets and outlier channels - what makes |mean| / std of real checkpoints' rows large - are not rounded with the rows; the consumer adds
+    // d[n] = sum_k centre[k] W'[n][k] back:  LN(x) W^T + b = rstd (rn16(x - centre) W'^T + d - mean s) + c.  Statistics stay those of x.  nullptr = not centred.
+    const float* ln_centre;         // EPI_BIAS_RESID_STATS / EPI_BIAS_ROWADD_STATS: [N] subtracted before the 16-bit rounding of xb
+    const float* ln_d;              // EPI_LNFOLD_*: [N] added to the accumulators
     int rs_prefetch_from;           // EPI_BIAS_RESID_STATS on the two-stage tile: workgroups with blockIdx.x >= this (> 0) load their residual rows BEFORE the
                                     // K loop (the workgroups a CU receives second, when every CU gets one before any gets two); 0 = off.  gemm_kernel.h: RsPrefetch
     int debug;                      // microbenchmark ablations only (0 in the product): 1 = no DMA in the K loop, 2 = no MFMA
@@ -94,6 +99,8 @@ struct MlpFusedParams {
     float* out; int ldo;                 // [M, D] f32 (may alias resid)
     bf16_t* xb; int ldxb;                // stats_out: 16-bit copy of the new rows (may alias X: a workgroup reads its rows before it writes them)
     float2* ln_part_out;                 // stats_out: their pairs (may alias ln_part_in)
+    const float* d1;                     // [Mlp] or nullptr: X holds rn16(x - centre); d1[n] = sum_k centre[k] W1'[n][k] is added to the up product (GemmParams::ln_d)
+    const float* centre_out;             // [D] or nullptr: stats_out writes xb = rn16(new rows - centre_out) (GemmParams::ln_centre)
     int M, D, Mlp;
     int f16;                             // 0: bf16 operands, 1: IEEE f16
     int split;                           // 0; 1: both weight matrices are hi / lo pairs; 2: only the up weight (IVIT_PRECISION_F16X's default split set)
@@ -174,9 +181,11 @@ hipError_t launch_scale_vec(const float* in, float a, float* out, int n, hipStre
 constexpr int GEMM_LN_SLOTS = 32;   // 64-column statistics slots per row (dim <= 2048)
 hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, const float* gamma, const float* beta, const float* bias,
                                   bf16_t* wf, float* s_out, float* c_out, hipStream_t s, int f16 = 0);
-hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16 = 0, int row_step = 1);   // part: [rows][GEMM_LN_SLOTS] (sum, M2) pairs, as EPI_BIAS_RESID_STATS writes them
+hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16 = 0, int row_step = 1, const float* centre = nullptr);   // part: [rows][GEMM_LN_SLOTS] (sum, M2) pairs, as EPI_BIAS_RESID_STATS writes them
 // atomicMax(*out, max over rows of |mean| / sqrt(var + eps)) of a [rows, dim] f32 matrix; the caller zeroes *out
-hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, float eps, float* out, hipStream_t s);
+hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, float eps, const float* centre, float* out, hipStream_t s);   // out[0]: plain copy, out[1]: centred copy
+hipError_t launch_col_means(const float* x, int ldx, int rows, int dim, float* out, hipStream_t s);
+hipError_t launch_centre_dot(const bf16_t* w, int ld, int rows, int cols, int split, const float* centre, float* d, hipStream_t s, int f16);
 // strided row gather: out[i,:] = in[i*row_stride, :dim]  (the `cls` node)
 hipError_t launch_gather_rows(const float* in, int64_t row_stride, float* out, int rows, int dim, hipStream_t s);
 // f32 [rows, cols] -> bf16 [rows, ldo] (columns >= cols zero)

@@ -339,8 +339,9 @@ hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, c
 // j * 16 + fq * 4 .. + 3 (j = 0..3) one after the other from 0, then (s0 + s1) + (s2 + s3); M2 about sum / ncols by explicit fma
 // in that order - so a layer gives the same bits whether its input came out of the previous layer's MLP-down GEMM in the same call,
 // out of an earlier call (chained nodes, which then skip this kernel) or from the caller.
+// `centre` (nullptr = none): the 16-bit copy is rn16(x - centre[n]), as GemmParams::ln_centre; the pairs are those of x itself.
 __global__ __launch_bounds__(256) void ivit_row_stats_pairs(const float* __restrict__ x, int ldx, int rows, int dim, bf16_t* __restrict__ xb, int ldxb,
-                                                            float2* __restrict__ part, int f16, int row_step) {
+                                                            float2* __restrict__ part, int f16, int row_step, const float* __restrict__ centre) {
     const int nslots = (dim + 63) >> 6, per_row = nslots * 4;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int row = (int)(t / per_row);
@@ -366,11 +367,13 @@ __global__ __launch_bounds__(256) void ivit_row_stats_pairs(const float* __restr
         for (int r = 0; r < 4; ++r) if (n + r < dim) sum += v[j][r];
         if (live) {
             bf16_t* ob = xb + (size_t)row * ldxb + n;
+            float ct[4] = {0.f, 0.f, 0.f, 0.f};
+            if (centre) for (int r = 0; r < 4; ++r) if (n + r < dim) ct[r] = centre[n + r];
             if (n + 3 < dim) {
-                u32x2 pk = {pack16x2(f16, v[j][0], v[j][1]), pack16x2(f16, v[j][2], v[j][3])};
+                u32x2 pk = {pack16x2(f16, v[j][0] - ct[0], v[j][1] - ct[1]), pack16x2(f16, v[j][2] - ct[2], v[j][3] - ct[3])};
                 *reinterpret_cast<u32x2*>(ob) = pk;
             } else {
-                for (int r = 0; r < 4; ++r) if (n + r < dim) ob[r] = enc16(f16, v[j][r]);
+                for (int r = 0; r < 4; ++r) if (n + r < dim) ob[r] = enc16(f16, v[j][r] - ct[r]);
             }
         }
     }
@@ -389,18 +392,20 @@ __global__ __launch_bounds__(256) void ivit_row_stats_pairs(const float* __restr
     if (fq == 0 && live && ncols > 0) part[(size_t)row * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
 }
 
-hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16, int row_step) {
+hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16, int row_step, const float* centre) {
     if (dim % 4 || dim > 64 * GEMM_LN_SLOTS || row_step < 1) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
     const int64_t threads = (int64_t)rows * ((dim + 63) >> 6) * 4;
-    hipLaunchKernelGGL(ivit_row_stats_pairs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, ldx, rows, dim, xb, ldxb, part, f16, row_step);
+    hipLaunchKernelGGL(ivit_row_stats_pairs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, ldx, rows, dim, xb, ldxb, part, f16, row_step, centre);
     return hipGetLastError();
 }
 
-// Calibration of the LayerNorm fold (ivit_ln_fold_calibrate): max over rows of |mean| / std of the LayerNorm input.
-// The folded GEMM multiplies the UNCENTRED 16-bit copy of x, so its operand-rounding noise is sqrt(1 + (mean/std)^2)
-// times the unfolded form's; this statistic decides whether a weight set keeps the fold.  One wave per row, two passes.
-__global__ __launch_bounds__(256) void ivit_row_mean_ratio(const float* __restrict__ x, int ldx, int rows, int dim, float eps,
+// Calibration of the LayerNorm fold (ivit_ln_fold_calibrate).  The folded GEMM multiplies a 16-bit copy of the rows that is NOT centred per row: its
+// operand-rounding noise is rms(copy) / std(x) times that of the unfolded form, which rounds (x - mean) rstd.  For the plain copy rn16(x) that factor is
+// sqrt(1 + (mean / std)^2); for the centred copy rn16(x - centre) it is sqrt(meansq(x - centre) / var(x)).  The statistic is the factor as
+// sqrt(factor^2 - 1) (so that the uncentred one reads |mean| / std), max over rows: out[0] of the plain copy, out[1] of the centred copy
+// (centre = nullptr: out[1] = out[0]).  One wave per row.
+__global__ __launch_bounds__(256) void ivit_row_mean_ratio(const float* __restrict__ x, int ldx, int rows, int dim, float eps, const float* __restrict__ centre,
                                                            unsigned int* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -409,15 +414,68 @@ __global__ __launch_bounds__(256) void ivit_row_mean_ratio(const float* __restri
     float sum = 0.f;
     for (int c = lane; c < dim; c += 64) sum += xr[c];
     const float mean = wave_sum(sum) / (float)dim;
-    float sq = 0.f;
-    for (int c = lane; c < dim; c += 64) { const float d = xr[c] - mean; sq = fmaf(d, d, sq); }
-    const float ratio = fabsf(mean) / sqrtf(wave_sum(sq) / (float)dim + eps);
-    if (lane == 0) atomicMax(out, __float_as_uint(ratio));   // non-negative floats order like their bit patterns
+    float sq = 0.f, zq = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+        const float d = xr[c] - mean;
+        sq = fmaf(d, d, sq);
+        const float z = xr[c] - (centre ? centre[c] : 0.f);
+        zq = fmaf(z, z, zq);
+    }
+    const float var = wave_sum(sq) / (float)dim + eps;
+    const float ratio = fabsf(mean) / sqrtf(var);
+    const float zr = sqrtf(fmaxf(wave_sum(zq) / (float)dim / var - 1.0f, 0.f));
+    if (lane == 0) {   // non-negative floats order like their bit patterns (NaN above all of them: a non-finite statistic wins)
+        atomicMax(out, __float_as_uint(ratio));
+        atomicMax(out + 1, __float_as_uint(centre ? zr : ratio));
+    }
 }
 
-hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, float eps, float* out, hipStream_t s) {
+hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, float eps, const float* centre, float* out, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ivit_row_mean_ratio, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, rows, dim, eps, reinterpret_cast<unsigned int*>(out));
+    hipLaunchKernelGGL(ivit_row_mean_ratio, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, rows, dim, eps, centre, reinterpret_cast<unsigned int*>(out));
+    return hipGetLastError();
+}
+
+// Column means of [rows, dim] f32 rows -> out[dim] (the centre vector of a LayerNorm input; calibration only).  Deterministic: a block owns 64 columns,
+// its four waves walk the rows r = w, w + 4, ... in order with double accumulators, and the four partial sums are added in wave order.
+__global__ __launch_bounds__(256) void ivit_col_means(const float* __restrict__ x, int ldx, int rows, int dim, float* __restrict__ out) {
+    __shared__ double part[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (col < dim) for (int r = w; r < rows; r += 4) acc += (double)x[(size_t)r * ldx + col];
+    part[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && col < dim) out[col] = (float)((((part[0][col & 63] + part[1][col & 63]) + part[2][col & 63]) + part[3][col & 63]) / (double)rows);
+}
+
+hipError_t launch_col_means(const float* x, int ldx, int rows, int dim, float* out, hipStream_t s) {
+    if (rows <= 0 || dim <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivit_col_means, dim3(ceil_div(dim, 64)), dim3(256), 0, s, x, ldx, rows, dim, out);
+    return hipGetLastError();
+}
+
+// d[n] = sum_k centre[k] W'[n][k] over the 16-bit matrix the MFMA multiplies (GemmParams::ln_d): hi + lo where the rows are pairs (split = 1: hi / lo
+// interleaved per 64-column K-tile, engine.hip: Matrix).  One wave per row, double accumulation; calibration only.
+__global__ __launch_bounds__(256) void ivit_centre_dot(const bf16_t* __restrict__ w, int ld, int rows, int cols, int split, const float* __restrict__ centre,
+                                                       float* __restrict__ d, int f16) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* wr = w + (size_t)row * ld;
+    double acc = 0.0;
+    for (int k = lane; k < cols; k += 64) {
+        double wv;
+        if (split == 1) { const int i = (k >> 6) * 128 + (k & 63); wv = (double)dec16(f16, wr[i]) + (double)dec16(f16, wr[i + 64]); }
+        else wv = (double)dec16(f16, wr[k]);
+        acc += (double)centre[k] * wv;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) d[row] = (float)acc;
+}
+
+hipError_t launch_centre_dot(const bf16_t* w, int ld, int rows, int cols, int split, const float* centre, float* d, hipStream_t s, int f16) {
+    if (rows <= 0 || cols <= 0 || (split != 0 && split != 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivit_centre_dot, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w, ld, rows, cols, split, centre, d, f16);
     return hipGetLastError();
 }
 

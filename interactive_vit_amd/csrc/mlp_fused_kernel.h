@@ -171,6 +171,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
     bf16x8 xf[2][4][2] = {};   // X fragments [set = K-tile & 1][i][kk]: the next K-tile's reads return under this K-tile's MFMAs
     bf16x8 uf[4][2] = {};      // U fragments of the current hidden half [i][k-step of 32 hidden]
     float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = c4;   // fold vectors of the chunk's hidden columns 16 w + 4 fq ..
+    // centred operand rows (kernels.h: GemmParams::ln_d): the chunk's up-product accumulators start from d1 instead of zero (gemm_acc_init); the next
+    // chunk's four values are fetched during phase 2, where fewer registers are live
+    float4 dn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.d1) dn = *reinterpret_cast<const float4*>(p.d1 + 16 * wave + 4 * fq);
     auto read_x = [&](int kt, bf16x8 (&f)[4][2]) {
         if (DBG & 4) return;
         const char* b = smem + kt * 8192;
@@ -187,7 +191,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
         const int cn = c + 1 < nchunks ? c + 1 : 0;   // the last chunk's look-ahead re-loads chunk 0: valid memory, never used
         // ---------------- phase 1: acc1 = X . W1'[chunk]^T, one K-tile per step (split: hi, then lo against the same X fragments)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // (zeroed here, not after its epilogue: dead, not live, through phase 2)
+        for (int i = 0; i < 4; ++i) acc1[i] = f32x4{dn.x, dn.y, dn.z, dn.w};   // (set here, not after its epilogue: dead, not live, through phase 2)
         mlpf_static_for<P>([&](auto s_tag) {
             constexpr int s = decltype(s_tag)::value, kt = s / S1;
             if constexpr (s + 1 < P && (s + 1) % S1 == 0) read_x(kt + 1, xf[(kt + 1) & 1]);   // the next K-tile's fragments return under this step's MFMAs
@@ -253,7 +257,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
         read_u(0);
         mlpf_static_for<P2>([&](auto v_tag) {
             constexpr int v = decltype(v_tag)::value, t = v % G::NF, NQ = 2 * S2, b0 = NB1 + NQ * v;
-            if constexpr (v == G::NF) read_u(1);
+            if constexpr (v == G::NF) {
+                read_u(1);
+                if (p.d1) dn = *reinterpret_cast<const float4*>(p.d1 + cn * 128 + 16 * wave + 4 * fq);
+            }
             if constexpr (v == P2 - 1) {
                 read_x(0, xf[0]);   // the next chunk's first K-tile
                 if (IVIT_MLPF_TOUCH) asm volatile("" ::"v"(touch));   // (the value is never used; the load is long complete)
@@ -296,7 +303,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
     asm volatile("" : "+s"(m0e), "+v"(fre), "+v"(fqe));
     GemmParams gp{};
     gp.M = p.M; gp.N = p.D; gp.bias = p.b2; gp.resid = p.resid; gp.ldr = p.ldr; gp.out = p.out; gp.ldo = p.ldo;
-    gp.xb = p.xb; gp.ldxb = p.ldxb; gp.ln_part = p.ln_part_out;
+    gp.xb = p.xb; gp.ldxb = p.ldxb; gp.ln_part = p.ln_part_out; gp.ln_centre = p.centre_out;
     gp.epi = p.stats_out ? EPI_BIAS_RESID_STATS : EPI_BIAS_RESID_F32;
     // residual rows of the shared half slot first: they are in flight under the whole-slot epilogue below (the epilogue is a burst of dependent
     // memory round trips on a CU with nothing else resident: everything that can be requested at once is)
@@ -339,8 +346,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
                 if (row_ok[i]) *reinterpret_cast<float4*>(p.out + (size_t)mr * p.ldo + n0 + 16 * j + 4 * fqe) = make_float4(v[0], v[1], v[2], v[3]);
             }
             if (p.stats_out) {   // 16-bit copy: 16-byte stores through the fragment-pair lane swap, as the GEMM epilogue (the swap itself in every lane)
-                const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][0], accH[i][0][1]), OP::pack2(accH[i][1][0], accH[i][1][1]), false, false);
-                const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][2], accH[i][0][3]), OP::pack2(accH[i][1][2], accH[i][1][3]), false, false);
+                float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca;   // rn16(x - centre) where the next LayerNorm's operand rows are centred (kernels.h: ln_centre)
+                if (p.centre_out) {
+                    ca = *reinterpret_cast<const float4*>(p.centre_out + n0 + 4 * fqe);
+                    cb = *reinterpret_cast<const float4*>(p.centre_out + n0 + 16 + 4 * fqe);
+                }
+                const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][0] - ca.x, accH[i][0][1] - ca.y), OP::pack2(accH[i][1][0] - cb.x, accH[i][1][1] - cb.y), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][2] - ca.z, accH[i][0][3] - ca.w), OP::pack2(accH[i][1][2] - cb.z, accH[i][1][3] - cb.w), false, false);
                 u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
                 if (row_ok[i]) *reinterpret_cast<u32x4*>(p.xb + (size_t)mr * p.ldxb + n0 + (fqe & 1) * 16 + (fqe & ~1) * 4) = pk;
             }

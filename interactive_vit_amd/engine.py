@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ivit_profile_reset", "ivit_profile_class_count", "ivit_profile_class_name", "ivit_profile_read",
     "ivit_profile_kernel_count", "ivit_profile_kernel_read", "ivit_debug_layer_tap", "ivit_debug_weight_fp8", "ivit_ln_fold_calibrate",
     "ivit_forward_host_async", "ivit_host_wait", "ivit_comm_unique_id", "ivit_comm_init", "ivit_allgather_cls",
-    "ivit_forward_device_packed", "ivit_shard_layout", "ivit_allgather_rows", "ivit_layer_with_attn", "ivit_layer_with_attn_host", "ivit_fused_mlp", "ivit_split_set",
+    "ivit_forward_device_packed", "ivit_shard_layout", "ivit_allgather_rows", "ivit_layer_with_attn", "ivit_layer_with_attn_host", "ivit_fused_mlp", "ivit_split_set", "ivit_ln_fold_centres",
 )
 
 
@@ -466,9 +466,11 @@ class Engine:
         return int(self.lib.ivit_fused_mlp(self._h, int(batch)))
 
     def calibrate_ln_fold(self, images: torch.Tensor, threshold: float = 0.5) -> float:
-        """Guard of the LayerNorm fold for THIS weight set (include/ivit.h: ivit_ln_fold_calibrate): one forward of
-        `images` ([B,3,S,S] in [0,1]) with LayerNorm kernels, returns max |mean| / std over all LayerNorm input rows;
-        the engine keeps the fold only if that is <= threshold."""
+        """Calibration and guard of the LayerNorm fold for THIS weight set (include/ivit.h: ivit_ln_fold_calibrate): one forward of
+        `images` ([B,3,S,S] in [0,1]) with LayerNorm kernels; the per-channel means of every LayerNorm input become the centre vectors
+        the engine subtracts before rounding its 16-bit copies (IVIT_FOLD_CENTRE=0: none), and the guard statistic of the centred copy
+        is returned - the engine keeps the fold only if that is <= threshold.  `ln_fold_ratio_plain` afterwards holds the statistic of
+        the plain copy (max |mean| / std over the rows), `ln_centres()` the vectors."""
         batch, _ = self._split_batch(images, 0)
         xin = images.detach().to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
         stream = torch.cuda.current_stream(xin.device).cuda_stream
@@ -476,7 +478,21 @@ class Engine:
         self._check(self.lib.ivit_ln_fold_calibrate(self._h, batch, ctypes.c_void_p(xin.data_ptr()), ctypes.c_float(threshold),
                                                     ctypes.byref(ratio), ctypes.c_void_p(stream)))
         self.ln_fold = bool(self.lib.ivit_ln_fold(self._h, 1))
+        plain = ctypes.c_float(0.0)
+        self._check(self.lib.ivit_ln_fold_centres(self._h, None, 0, None, ctypes.byref(plain)))
+        self.ln_fold_ratio_plain = float(plain.value)
         return float(ratio.value)
+
+    def ln_centres(self) -> Optional[torch.Tensor]:
+        """The centre vectors of the LayerNorm inputs ([2 * layers, dim] f32: LN1 of layer 0, LN2 of layer 0, LN1 of layer 1, ...) when the
+        engine's 16-bit copies are centred (after calibrate_ln_fold), else None - what the rounding-aware oracle mirrors (LN_CENTRE)."""
+        n = 2 * self.cfg.layers * self.cfg.dim
+        buf = (ctypes.c_float * n)()
+        on = ctypes.c_int(0)
+        self._check(self.lib.ivit_ln_fold_centres(self._h, buf, n, ctypes.byref(on), None))
+        if not on.value:
+            return None
+        return torch.frombuffer(buf, dtype=torch.float32).clone().reshape(2 * self.cfg.layers, self.cfg.dim)
 
     def layer_with_attn(self, layer: int, x: torch.Tensor):
         """Encoder layer `layer` on a residual-stream input [N,D] / [B,N,D] with its attention map as a second result

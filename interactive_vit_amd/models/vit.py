@@ -173,8 +173,10 @@ class HipBackend:
         self._module = VitParameters(state_dict)
         self.engine = Engine(cfg, state_dict, device=device, max_batch=max_batch, precision=precision)
         # A plugin takes whatever checkpoint it is given (reference static/models/vgg16.py:12-14).  The LayerNorm fold
-        # of the engine is only as accurate as the unfolded form while |mean| / std of the residual-stream rows is
-        # small, a property of the weights: measure it once on sample images and let the engine keep or drop the fold.
+        # of the engine is only as accurate as the unfolded form while the 16-bit copies of the residual-stream rows it multiplies
+        # are small against the rows' spread, a property of the weights: one calibration forward on sample images takes the
+        # per-channel means of every LayerNorm input as the centre vectors of those copies (real checkpoints' offsets and outlier
+        # channels are constant across rows), measures what is left, and lets the engine keep or drop the fold.
         # `calibration_images` ([B,3,S,S] in [0,1], B <= max_batch): real sample pictures of the deployment when the operator has some
         # (a real checkpoint's residual stream depends on its inputs); else two seeded synthetic images.  `ln_fold_threshold`: the
         # largest |mean| / std the fold is kept for (engine default 0.5); the measured ratio is kept in `ln_fold_ratio`.

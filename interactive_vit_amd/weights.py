@@ -68,6 +68,24 @@ def init_weights(cfg: VitConfig, seed: int = 0, mode: str = "spec") -> Dict[str,
     return sd
 
 
+def realistic_statistics_weights(cfg: VitConfig, seed: int = 21, hot=(2.0, -2.5, 3.0, 4.0)) -> Dict[str, torch.Tensor]:
+    """A random weight set with the STATISTICS of a trained checkpoint rather than N(0, 0.02^2) (no checkpoint can be fetched here): every channel of
+    the position embedding offset by 0.6 (row mean of the residual stream ~ 3 sigma), a few 50 ... 100 sigma outlier channels, LayerNorm gains
+    0.3 ... 3 and offsets ~ +-0.5.  What the LayerNorm-fold calibration (include/ivit.h: ivit_ln_fold_calibrate) is tested and benchmarked on
+    (tests/test_gpu_configs.py, bench.py --weights realistic)."""
+    sd = init_weights(cfg, seed=seed, mode="rich")
+    g = torch.Generator().manual_seed(seed + 100)
+    pos = sd["encoder.pos_embedding"]
+    pos += 0.6
+    idx = torch.randperm(cfg.dim, generator=g)[:len(hot)]
+    pos[..., idx] += torch.tensor(hot)
+    for i in range(cfg.layers):
+        for ln in ("ln_1", "ln_2"):
+            sd[f"{layer_prefix(i)}{ln}.weight"] = torch.exp(torch.randn(cfg.dim, generator=g) * 0.6).clamp(0.3, 3.0)
+            sd[f"{layer_prefix(i)}{ln}.bias"] = torch.randn(cfg.dim, generator=g) * 0.25
+    return sd
+
+
 def load_state_dict_file(path: str, cfg: VitConfig) -> Dict[str, torch.Tensor]:
     """A LOCAL checkpoint in torchvision ``VisionTransformer`` key names -> the f32 state dict ``ivit_set_weight`` takes.
 

@@ -289,7 +289,7 @@ def attention_map(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> to
     if emulate and LN_FOLD:
         b, n, d = x.shape
         qkv = rnd(folded_linear(x, sd[pre + "self_attention.in_proj_weight"], sd[pre + "self_attention.in_proj_bias"],
-                                sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], cfg.ln_eps, "w_qkv", _split("qkvw")), True, point="qkv")
+                                sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], cfg.ln_eps, "w_qkv", _split("qkvw"), _centre(2 * i)), True, point="qkv")
         return attention_core(qkv, cfg, True)[1]
     h = rnd(layer_norm(x, _w(sd, pre + "ln_1.weight", dt), _w(sd, pre + "ln_1.bias", dt), cfg.ln_eps), emulate, point="x")
     return attention(h, sd, i, cfg, return_probs=True, emulate=emulate)[1]
@@ -303,6 +303,15 @@ def attention_map(x: torch.Tensor, sd, i: int, cfg, emulate: bool = False) -> to
 # ViT-B/16).  Tests / bench / smoke set this from Engine.ln_fold; the plain (emulate=False) forward never looks at it.
 LN_FOLD = False
 
+# The engine's centred operand copies (round 5; include/ivit.h: ivit_ln_fold_calibrate): None, or a [2 * layers, D] tensor of per-channel
+# centre vectors m (row 2 i: LN1 of layer i, row 2 i + 1: LN2) - the folded GEMM then multiplies rn16(x - m) and adds W' m back:
+# rstd ((rn16(x - m) + m) W'^T - mean s) + c.  Tests / bench / smoke set it from Engine.ln_centres(); only the LN_FOLD form looks at it.
+LN_CENTRE = None
+
+
+def _centre(site: int):
+    return None if LN_CENTRE is None else LN_CENTRE[site]
+
 
 # How the folded weight W' = W . diag(gamma) is prepared.  "twice" = what the ENGINE does for every non-split matrix
 # (ivit_fold_ln_weights): from its 16-bit copy of W, rounded again.  "once" = from the f32 matrix, one rounding - a STUDY-ONLY
@@ -312,8 +321,9 @@ FOLD_ROUNDING = "twice"
 
 
 def folded_linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
-                  wpoint=None, wsplit: bool = False) -> torch.Tensor:
-    """LayerNorm(x) @ w.T + b as the engine's folded GEMM evaluates it (x: [..., D] in the compute dtype)."""
+                  wpoint=None, wsplit: bool = False, centre=None) -> torch.Tensor:
+    """LayerNorm(x) @ w.T + b as the engine's folded GEMM evaluates it (x: [..., D] in the compute dtype; centre: the per-channel
+    vector m the engine subtracts before the 16-bit rounding of its operand copy, or None)."""
     dt = x.dtype
     if not _on(wpoint):
         wb = w.to(dt)
@@ -331,8 +341,12 @@ def folded_linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma: torc
     c = wb @ beta.to(dt) + b.to(dt)
     mu = x.mean(dim=-1, keepdim=True)
     rstd = 1.0 / torch.sqrt(((x - mu) ** 2).mean(dim=-1, keepdim=True) + eps)
-    xb = rnd(x, True, point="x")
-    return rstd * (xb @ wf.t() - mu * s) + c
+    if centre is None:
+        xb = rnd(x, True, point="x")
+        return rstd * (xb @ wf.t() - mu * s) + c
+    m = centre.to(torch.float32)
+    xb = rnd((x.to(torch.float32) - m).to(dt), True, point="x")      # the engine subtracts in f32, then rounds to 16 bits
+    return rstd * ((xb @ wf.t() + m.to(dt) @ wf.t()) - mu * s) + c
 
 
 def _encoder_layer_fold(x: torch.Tensor, sd, i: int, cfg) -> torch.Tensor:
@@ -341,7 +355,7 @@ def _encoder_layer_fold(x: torch.Tensor, sd, i: int, cfg) -> torch.Tensor:
     b, n, d = x.shape
     hd = cfg.head_dim
     qkv = rnd(folded_linear(x, sd[pre + "self_attention.in_proj_weight"], sd[pre + "self_attention.in_proj_bias"],
-                            sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], cfg.ln_eps, "w_qkv", _split("qkvw")), True, point="qkv")
+                            sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"], cfg.ln_eps, "w_qkv", _split("qkvw"), _centre(2 * i)), True, point="qkv")
     q, k, v = [t.reshape(b, n, cfg.heads, hd).transpose(1, 2) for t in qkv.split(d, dim=-1)]
     sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
     a = _pv_emulated(sc, v).transpose(1, 2).reshape(b, n, d)
@@ -349,7 +363,7 @@ def _encoder_layer_fold(x: torch.Tensor, sd, i: int, cfg) -> torch.Tensor:
         x = x + _split_product(a, sd[pre + "self_attention.out_proj.weight"].to(dt)) + _w(sd, pre + "self_attention.out_proj.bias", dt)
     else:
         x = x + rnd(a, True, point="att") @ _w(sd, pre + "self_attention.out_proj.weight", dt, True, "w_proj").t() + _w(sd, pre + "self_attention.out_proj.bias", dt)
-    u = rnd(gelu_erf(folded_linear(x, sd[pre + "mlp.0.weight"], sd[pre + "mlp.0.bias"], sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"], cfg.ln_eps, "w_mlp1", _split("mlp1w"))), True, point="gelu")
+    u = rnd(gelu_erf(folded_linear(x, sd[pre + "mlp.0.weight"], sd[pre + "mlp.0.bias"], sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"], cfg.ln_eps, "w_mlp1", _split("mlp1w"), _centre(2 * i + 1))), True, point="gelu")
     return x + u @ _w16(sd, pre + "mlp.3.weight", dt, True, "w_mlp2", _split("mlp2w")).t() + _w(sd, pre + "mlp.3.bias", dt)
 
 
