@@ -239,6 +239,7 @@ struct ivit_engine {
     // LayerNorm fold (bf16 data path; IVIT_FOLD_LN=0 keeps the LayerNorm kernel): see run_layer
     uint64_t stats_token = 0; int stats_batch = 0;   // resident_token of the host-call output whose LayerNorm statistics pairs / 16-bit copy are in the workspace
     bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
+    int gemm_group_n = 0;           // study knob IVIT_GEMM_GROUP_N (>= 3): column-panel width of the 256 x 256 tiles' block -> tile map (default 8: gemm_kernel.h: GEMM_GROUP_N)
     bool fused_mlp = false;         // LN2 -> MLP up -> GELU -> MLP down -> residual in ONE launch where the shape allows (IVIT_FUSED_MLP=0 switches it off)
     // Centred operand copy (round 5): one calibrated per-channel vector per LayerNorm input - site 2 i = LN1 of layer i, 2 i + 1 = LN2 - subtracted before the
     // 16-bit rounding of the rows the folded GEMMs multiply (kernels.h: GemmParams::ln_centre / ln_d).  Zero and unused until ivit_ln_fold_calibrate has run.
@@ -412,6 +413,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         const char* fl = getenv("IVIT_FOLD_LN");
         e->fold_ln = !(fl && atoi(fl) == 0) && !precision_is_fp8(cfg->precision) && cfg->dim <= 64 * GEMM_LN_SLOTS;
         e->fold_always = fl && atoi(fl) == 2;
+        const char* gg = getenv("IVIT_GEMM_GROUP_N");
+        e->gemm_group_n = gg && atoi(gg) >= 3 ? atoi(gg) : 0;
         const char* fc = getenv("IVIT_FOLD_CENTRE");
         e->centre_on = !(fc && atoi(fc) == 0);
         const char* fm = getenv("IVIT_FUSED_MLP");
@@ -675,6 +678,7 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
     p.A = A; p.lda = lda; p.W = W.p; p.ldw = W.ld; p.M = M; p.N = W.rows; p.K = W.ld; p.f16 = e->f16; p.a_wrap = W.a_wrap; p.a_shift = W.a_shift;
     p.bias = bias; p.epi = epi; p.out = out; p.ldo = ldo; p.resid = resid; p.ldr = ldr;
     p.rowadd = rowadd; p.ldra = ldra; p.grp_in = grp_in; p.grp_out = grp_out; p.grp_off = grp_off;
+    p.debug = e->gemm_group_n;   // (0 in the product; >= 3: the 256 x 256 kernels take it as their column-panel width)
     if (lf) { p.ln_part = lf->part; p.ln_stats = lf->stats; p.xb = lf->xb; p.ldxb = e->D; p.ln_s = lf->s; p.ln_eps = e->cfg.ln_eps; p.ln_dim = e->D; p.ln_centre = lf->centre; p.ln_d = lf->d; }
     const bool bf_out = (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16 || epi == EPI_LNFOLD_BF16 || epi == EPI_LNFOLD_GELU_BF16);
     const bool resid_in = (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_RESID_STATS);

@@ -103,7 +103,12 @@ __device__ __forceinline__ void gemm256s_body(const GemmParams& p, char* smem) {
     const int fr = lane & 15, fq = lane >> 4;
 
     int tm, tn;
-    tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), ceil_div(p.N, T::BN), tm, tn, p.debug >= 3 ? p.debug : GEMM_GROUP_N);
+    // column panels of at most six 256-wide tiles, balanced (9 column tiles: 5 + 4, 12: 6 + 6, 16: 6 + 5 + 5 as 6 / 6 / 4): the ~32 tiles an XCD runs at once
+    // then cover ~6 x 5 row / column tiles - 4.3 MB of operands at K = 768 against 4.7 MB for the 8-wide panels of the smaller tiles' rule.  In the
+    // forward, same box (round 5, IVIT_GEMM_GROUP_N): ViT-B/16 B = 64 QKV 53.1 -> 52.4 us, +0.5 % on the step; ViT-L/16-384 QKV 413 -> 409, MLP up 623 -> 618 us
+    const int tiles_n = ceil_div(p.N, T::BN);
+    const int group = p.debug >= 3 ? p.debug : ceil_div(tiles_n, ceil_div(tiles_n, 6));
+    tile_coords(xcd_tile(blockIdx.x, gridDim.x), ceil_div(p.M, T::BM), tiles_n, tm, tn, group);
     const int m0 = tm * T::BM;
     const int n0 = tn * T::BN;
 

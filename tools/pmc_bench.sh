@@ -10,7 +10,7 @@ TAG=${1:-r01}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT profiles
 export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-tolerance-mode $*"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-tolerance-mode --no-layernorm-leg $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.log 2>&1

@@ -2,7 +2,7 @@
 # SQ/TCC counters per kernel over a short bench run (separate passes).  usage: tools/pmc_kernels.sh <outdir> [tag]
 # with a tag: also writes profiles/<tag>_pmc_mfma.json (MFMA utilisation, wave-cycle split, L2 hit rate per kernel)
 OUT=${1:-gpurun_out/pmc_k}; TAG=$2; mkdir -p $OUT profiles; export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-tolerance-mode"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-tolerance-mode --no-layernorm-leg"
 run() { rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $OUT/$2 -- python3 bench.py $ARGS > $OUT/$2.log 2>&1 || echo "pass $2 failed"; }
 run "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" sq
 run "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE" sq2
