@@ -386,6 +386,7 @@ def main():
         sd = init_weights(cfg, seed=0, mode="spec")             # replicated weights, seed 0
     eng = Engine(cfg, sd, device=local_rank, max_batch=B, precision=args.precision)
     fold_ratio = None
+    centred_any = False
     peak = PEAK_FP8_TFLOPS if args.precision == "fp8" else PEAK_BF16_TFLOPS
     if args.precision == "fp8m":   # MLP up / down on the fp8 MFMA, the rest of the GEMM class on the bf16 one: the time-weighted (harmonic) blend
         mlp = 2.0 * cfg.mlp / (4.0 * cfg.dim + 2.0 * cfg.mlp)      # share of the encoder GEMM FLOPs that is MLP up + down
@@ -400,6 +401,7 @@ def main():
         # the 16-bit copies + the guard - on sample images, outside the timed region.  The timed forward then runs the kernels a deployment runs.
         # (every rank calibrates on rank 0's first images: an image's result must not depend on the shard it lands in)
         fold_ratio = eng.calibrate_ln_fold(synthetic_images(min(4, B), cfg, seed=1234, device=f"cuda:{local_rank}"))
+        centred_any = eng.ln_centres() is not None
     # the ONE collective of the path is issued by the engine itself through RCCL (include/ivit.h: ivit_allgather_cls); torch's
     # process group only carries the communicator id, the barriers and the max-over-ranks of the timing (IVIT_GATHER=torch
     # routes the all-gather through torch.distributed instead: the round-1 path, kept for A/B)
@@ -651,6 +653,7 @@ def main():
             ln_leg = {"error": repr(ex)}
 
     eng_ratio_plain = getattr(eng, "ln_fold_ratio_plain", 0.0)
+
     if use_dist:
         dist.barrier()
     if rank == 0:
@@ -669,8 +672,9 @@ def main():
                        "batch_per_gpu": B, "global_batch": total, "tokens": cfg.tokens,
                        "gflop_per_image": round(flops_img / 1e9, 3), "parallelism": f"dp{world}",
                        "weights": "random init N(0,0.02^2) seed 0" if args.weights == "spec" else "random, real-checkpoint statistics (weights.realistic_statistics_weights seed 21)",
-                       "layernorm": ("folded into the consuming GEMMs" + (f"; 16-bit copies centred about calibrated per-channel means, guard statistic {fold_ratio:.3f} "
-                                     f"(plain copies {eng_ratio_plain:.3f})" if fold_ratio is not None else "")) if folded else "kernel"},
+                       "layernorm": ("folded into the consuming GEMMs" + (f"; guard statistic {fold_ratio:.3f} (plain copies {eng_ratio_plain:.3f}); 16-bit copies "
+                                     + ("centred about calibrated per-channel means" if centred_any else "plain (nothing to gain from centring)")
+                                     if fold_ratio is not None else "")) if folded else "kernel"},
             "roofline": roofline, "cpu_baseline": cpu, "tolerance_mode": tolerance, "layernorm_kernels": ln_leg, "step_ms": step_ms, "pcie_inclusive": pcie, "parity": parity,
         }
         sys.stdout.flush()

@@ -134,8 +134,10 @@ int ivit_split_set(const ivit_engine* e);
  *     LN(x) W^T + b = rstd (rn16(x - m) W'^T + d - mean s) + c        (statistics mean / rstd are those of x itself; m = 0 reproduces rounds 3-4).
  * The guard statistic is the noise factor as sqrt(factor^2 - 1) - for the plain copy |mean| / std - max over the rows of a LayerNorm input.  A
  * population mean does not suit every row (a class-token row that lacks the patch rows' common offset gets WORSE when that offset is subtracted), so
- * each of the 2 * layers inputs keeps its vector only where the centred copies' statistic is below the plain copies' - otherwise that input stays
- * on the plain copy (vector zero).  *max_ratio (optional) receives the maximum over the inputs of the statistic of the copy each one uses, and the fold
+ * each of the 2 * layers inputs keeps its vector only where the centred copies' statistic is below the plain copies' - and, on the bf16 data path,
+ * only where the plain copies' statistic exceeds 0.25 (the centred epilogues cost ~2 % of a ViT-B/16 step; rows that are nearly centred anyway gain
+ * nothing measurable in bf16; the f16 data paths and IVIT_FOLD_CENTRE=2 centre wherever it lowers the statistic) - otherwise that input stays on the
+ * plain copy (vector zero).  *max_ratio (optional) receives the maximum over the inputs of the statistic of the copy each one uses, and the fold
  * is kept for this engine only if it is <= threshold (0.5: at most 12 % more rounding noise than the LayerNorm kernels); otherwise every later call
  * uses the LayerNorm kernels (ivit_ln_fold then answers 0).
  * IVIT_FOLD_CENTRE=0 in the environment at ivit_create keeps the plain copy (guard on |mean| / std, as before).  ivit_set_weight drops the vectors

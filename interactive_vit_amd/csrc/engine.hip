@@ -245,6 +245,9 @@ struct ivit_engine {
     // 16-bit rounding of the rows the folded GEMMs multiply (kernels.h: GemmParams::ln_centre / ln_d).  Zero and unused until ivit_ln_fold_calibrate has run.
     float* centre = nullptr;        // [2 L][D]
     bool centre_on = true;          // IVIT_FOLD_CENTRE=0: calibrate the guard on the plain copy, as rounds 3-4 did
+    float centre_min = 0.25f;       // a site takes its vector only if the plain copies' statistic exceeds this (and the centred one is lower).  The centred epilogues cost
+                                    // 2.1 % of a ViT-B/16 B = 64 step (profiles/r05_fused_mlp.txt): on weights whose rows are already nearly centred (seeded: 0.14, i.e. 1 % more
+                                    // noise than LayerNorm kernels) that buys nothing in bf16.  IVIT_FOLD_CENTRE=2 (and the f16 data paths, where the last 1e-4 counts): 0
     bool centred = false;           // some site's vector is in use
     std::vector<char> site_on;      // [2 L]: this site's copies are centred (the calibration keeps a vector only where it lowers the site's guard statistic:
                                     // rows that differ from the population - a class-token row without the patches' common offset - get WORSE when a population mean is subtracted)
@@ -417,6 +420,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         e->gemm_group_n = gg && atoi(gg) >= 3 ? atoi(gg) : 0;
         const char* fc = getenv("IVIT_FOLD_CENTRE");
         e->centre_on = !(fc && atoi(fc) == 0);
+        if ((fc && atoi(fc) == 2) || (!fc && e->f16)) e->centre_min = 0.f;
         const char* fm = getenv("IVIT_FUSED_MLP");
         e->fused_mlp = e->fold_ln && !(fm && atoi(fm) == 0) && mlp_fused_supported(1, cfg->dim, cfg->mlp, e->f16, mlp_split_mode(e));
         if (e->split < 1 || e->split > ivit_engine::MAX_SPLIT) e->split = 1;
@@ -1476,7 +1480,7 @@ extern "C" int ivit_ln_fold_calibrate(ivit_engine* e, int batch, const void* in,
         if (hipMemcpyAsync(stat.data(), dev, stat.size() * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = fail("reading the calibration statistics failed"); break; }
         // a site keeps its vector only where that LOWERS its statistic (a non-finite one never compares below); the others go back to the plain copy
         for (int sidx = 0; sidx < sites && !rc; ++sidx) {
-            on[sidx] = e->centre_on && stat[2 * sidx + 1] < stat[2 * sidx];
+            on[sidx] = e->centre_on && stat[2 * sidx] > e->centre_min && stat[2 * sidx + 1] < stat[2 * sidx];
             if (!on[sidx] && hipMemsetAsync(e->centre + (size_t)sidx * e->D, 0, (size_t)e->D * sizeof(float), st) != hipSuccess) rc = fail("hipMemsetAsync failed");
         }
         // d = W' . centre for the folded GEMM behind every centred site, over the 16-bit matrices as they are multiplied

@@ -498,7 +498,7 @@ __device__ __forceinline__ void rs_prefetch_load(const GemmParams& p, int m_base
         for (int j = 0; j < T::FN; ++j) x[i][j] = *reinterpret_cast<const float4*>(src + (size_t)i * 16 * p.ldr + j * 16);
 }
 
-template <class T, class OP, int G>
+template <class T, class OP, int G, bool HOLD_CT = false>
 __device__ __forceinline__ void gemm_epilogue_resid_stats_interior(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
                                                                    const typename RsPrefetch<T>::Rows& pfx, bool pf_have) {
     static_assert(T::FN * 16 == 64 && T::FN % 2 == 0, "one statistics slot per wave column; fragment pairs for the 16-byte stores");
@@ -541,8 +541,24 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats_interior(const GemmPar
             for (int j = 0; j < T::FN; ++j)
                 if (ii < T::FM && !(pre && ii < PR)) x[0][ii][j] = *reinterpret_cast<const float4*>(src[ii] + j * 16);
     }
+    // The centre vector of this wave's columns is (re)loaded per residual-load group, AHEAD of the next group's residual loads: vector-memory results return in
+    // order, so a load issued behind them makes the copy of THIS group wait for the NEXT group's residual rows (the one-row-ahead pipeline gone: proj + 2.3 us per
+    // launch).  Re-read per group from L1 rather than held across the tile: the 168-register tiles have no room for 16 more.  The three-per-CU 128 x 128 tile - FM = 4
+    // with two rows of residual loads in flight - has no room for them even that long (36 bytes of scratch): it reads them behind the statistics
+    // HOLD_CT (the two-per-CU tile: 256 registers a lane): loaded ONCE for the tile - every re-read is another 4 KiB per wave through the CU's vector-memory return
+    // path, which is what an epilogue burst is bound by (five re-reads per 160 x 128 tile: proj + 2.3 us per launch)
+    constexpr bool CT_EARLY = !(T::FM == 4 && G == 2);
+    float4 ct[T::FN];
+    if (centred && HOLD_CT) {
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) ct[j] = *reinterpret_cast<const float4*>(p.ln_centre + n_base + j * 16 + fq * 4);
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+        if (centred && CT_EARLY && !HOLD_CT) {
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) ct[j] = *reinterpret_cast<const float4*>(p.ln_centre + n_base + j * 16 + fq * 4);
+        }
         if (g + 1 < NG) {
 #pragma unroll
             for (int ii = 0; ii < G; ++ii)
@@ -576,7 +592,19 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats_interior(const GemmPar
                     *reinterpret_cast<u32x4*>(ob + (j + (fq & 1)) * 16 + (fq & ~1) * 4) = pk;
                 }
             };
-            if (!centred && !IVIT_RS_COPY_LAST) store_copy();   // plain copy: beside the f32 stores, as rounds 3-4
+            auto store_copy_centred = [&]() {   // the same on x - centre, the row's values left as they are (the statistics below are those of x)
+#pragma unroll
+                for (int j = 0; j < T::FN; j += 2) {
+                    const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(acc[i][j][0] - ct[j].x, acc[i][j][1] - ct[j].y), OP::pack2(acc[i][j + 1][0] - ct[j + 1].x, acc[i][j + 1][1] - ct[j + 1].y), false, false);
+                    const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(acc[i][j][2] - ct[j].z, acc[i][j][3] - ct[j].w), OP::pack2(acc[i][j + 1][2] - ct[j + 1].z, acc[i][j + 1][3] - ct[j + 1].w), false, false);
+                    u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};
+                    *reinterpret_cast<u32x4*>(ob + (j + (fq & 1)) * 16 + (fq & ~1) * 4) = pk;
+                }
+            };
+            // the copy goes out beside the f32 stores (its stores then overlap the statistics' shuffle chains: behind them, the centred form cost proj 2.4 us per
+            // launch) - except on the tile that has no room for the centre vector that early, which subtracts in place after the statistics
+            if (!centred && !IVIT_RS_COPY_LAST) store_copy();
+            else if (centred && CT_EARLY && !IVIT_RS_COPY_LAST) store_copy_centred();
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float lmean = sum / 64.0f;
@@ -588,16 +616,15 @@ __device__ __forceinline__ void gemm_epilogue_resid_stats_interior(const GemmPar
             m2 += __shfl_xor(m2, 16, 64);
             m2 += __shfl_xor(m2, 32, 64);
             if (fq == 0) p.ln_part[(size_t)mr * GEMM_LN_SLOTS + slot] = make_float2(sum, m2);
-            // 16-bit copy, last: the row's values are dead after the statistics, so a centred copy (rn16(x - centre[n])) subtracts IN PLACE, one column quad at a
-            // time (re-read per fragment row from L1: held across the rows, or subtracted beside live values, the vector spilled in the 168-register tiles)
-            if (centred) {
+            // 16-bit copy, last: the row's values are dead after the statistics, so a centred copy (rn16(x - centre[n])) subtracts IN PLACE
+            if (centred && (!CT_EARLY || IVIT_RS_COPY_LAST)) {
 #pragma unroll
                 for (int j = 0; j < T::FN; ++j) {
-                    const float4 ct = *reinterpret_cast<const float4*>(p.ln_centre + n_base + j * 16 + fq * 4);
-                    acc[i][j][0] -= ct.x; acc[i][j][1] -= ct.y; acc[i][j][2] -= ct.z; acc[i][j][3] -= ct.w;
+                    if (!CT_EARLY) ct[j] = *reinterpret_cast<const float4*>(p.ln_centre + n_base + j * 16 + fq * 4);
+                    acc[i][j][0] -= ct[j].x; acc[i][j][1] -= ct[j].y; acc[i][j][2] -= ct[j].z; acc[i][j][3] -= ct[j].w;
                 }
             }
-            if (centred || IVIT_RS_COPY_LAST) store_copy();
+            if ((centred && !CT_EARLY) || IVIT_RS_COPY_LAST) store_copy();
         }
     }
 }
@@ -759,7 +786,7 @@ __device__ __forceinline__ void ln_tile_stats_prefetch(const GemmParams& p, int 
 // EK = 0: the classic 16-bit / fp8 output epilogues (kind chosen at run time); 3: the classic f32 output epilogues; 1: EPI_BIAS_RESID_STATS; 2: EPI_LNFOLD_*.
 // (One kernel per classic kind was tried too: no gain at the ViT-B shapes, 5-15 % slower at the ViT-H shapes.)
 // RSG: fragment rows per residual-load group of the interior EPI_BIAS_RESID_STATS epilogue (register budget of the calling kernel)
-template <class T, int EK, class OP = OpBf16, int RSG = T::FM>
+template <class T, int EK, class OP = OpBf16, int RSG = T::FM, bool HOLD_CT = false>
 __device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 (&acc)[T::FM][T::FN], int m_base, int n_base, int fr, int fq,
                                                      const float2* tile_stats, const typename RsPrefetch<T>::Rows& pfx, bool pf_have) {
     const bool interior = (m_base + T::FM * 16 <= p.M) && (n_base + T::FN * 16 <= p.N);
@@ -769,7 +796,7 @@ __device__ __forceinline__ void gemm_epilogue_family(const GemmParams& p, f32x4 
 #ifdef IVIT_GEMM_ABLATIONS   // A/B in one binary (tools/gemm_bench argv[5] = 7, IVIT_OLD_EPI=1 with tools/libivit_abl.so): round 3's row-by-row form
         if (interior && p.debug == 7) { gemm_epilogue_resid_stats<T, true, OP>(p, acc, m_base, n_base, fr, fq); return; }
 #endif
-        if (interior) gemm_epilogue_resid_stats_interior<T, OP, RSG>(p, acc, m_base, n_base, fr, fq, pfx, pf_have);
+        if (interior) gemm_epilogue_resid_stats_interior<T, OP, RSG, HOLD_CT>(p, acc, m_base, n_base, fr, fq, pfx, pf_have);
         else gemm_epilogue_resid_stats<T, false, OP>(p, acc, m_base, n_base, fr, fq);
     } else {
         if (interior) gemm_epilogue_lnfold<T, true, OP>(p, acc, m_base, n_base, fr, fq, tile_stats);
@@ -953,7 +980,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem) {
     }
     for (int t = t_first; t < nt; ++t) ktile(t, std::false_type{});
     IVIT_BODY_STAMP(2);
-    gemm_epilogue_family<T, EK, OP, IVIT_RSG_2STAGE>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16, rs_x, rs_have);
+    gemm_epilogue_family<T, EK, OP, IVIT_RSG_2STAGE, true>(p, acc, m0 + wr * T::FM * 16, n0 + wc * T::FN * 16, fr, fq, tile_stats + wr * T::FM * 16, rs_x, rs_have);
     IVIT_BODY_STAMP(3);
 #ifdef IVIT_GEMM_ABLATIONS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -332,6 +332,13 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
         float* xch = reinterpret_cast<float*>(ubuf + (nchunks & 1) * G::U_BYTES) + (wave >> 1) * 1024;   // three arrays of [4 i][64 lanes] per wave pair
 #pragma unroll
         for (int j = 0; j < 2; ++j) bias_h[j] = *reinterpret_cast<const float4*>(p.b2 + n0 + 16 * j + 4 * fqe);
+        // rn16(x - centre) where the next LayerNorm's operand rows are centred (kernels.h: ln_centre); requested ahead of the rows' stores (loads and stores
+        // return through one in-order counter)
+        float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca;
+        if (p.stats_out && p.centre_out) {
+            ca = *reinterpret_cast<const float4*>(p.centre_out + n0 + 4 * fqe);
+            cb = *reinterpret_cast<const float4*>(p.centre_out + n0 + 16 + 4 * fqe);
+        }
         float sum[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -346,11 +353,6 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
                 if (row_ok[i]) *reinterpret_cast<float4*>(p.out + (size_t)mr * p.ldo + n0 + 16 * j + 4 * fqe) = make_float4(v[0], v[1], v[2], v[3]);
             }
             if (p.stats_out) {   // 16-bit copy: 16-byte stores through the fragment-pair lane swap, as the GEMM epilogue (the swap itself in every lane)
-                float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca;   // rn16(x - centre) where the next LayerNorm's operand rows are centred (kernels.h: ln_centre)
-                if (p.centre_out) {
-                    ca = *reinterpret_cast<const float4*>(p.centre_out + n0 + 4 * fqe);
-                    cb = *reinterpret_cast<const float4*>(p.centre_out + n0 + 16 + 4 * fqe);
-                }
                 const auto lo = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][0] - ca.x, accH[i][0][1] - ca.y), OP::pack2(accH[i][1][0] - cb.x, accH[i][1][1] - cb.y), false, false);
                 const auto hi = __builtin_amdgcn_permlane16_swap(OP::pack2(accH[i][0][2] - ca.z, accH[i][0][3] - ca.w), OP::pack2(accH[i][1][2] - cb.z, accH[i][1][3] - cb.w), false, false);
                 u32x4 pk = {lo[0], hi[0], lo[1], hi[1]};

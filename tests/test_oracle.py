@@ -160,6 +160,37 @@ def test_emulate_mode_with_every_rounding_point_off_is_the_plain_forward(ln_fold
     assert err <= 1e-6, err
 
 
+def test_centred_fold_algebra_is_the_plain_layer():
+    """Round 5: the engine's folded GEMMs multiply rn16(x - m) and add W' m back (include/ivit.h: ivit_ln_fold_calibrate); the oracle mirrors the
+    vectors through LN_CENTRE.  With every rounding point off, ANY centre vectors must leave an encoder layer where the plain forward puts it -
+    to f32 round-off of the one subtraction the engine makes in f32 - and with the roundings on, centring must not move the layer further from
+    the plain forward than the plain copy does when the rows carry a large common offset."""
+    cfg = small_config()
+    sd = init_weights(cfg, seed=3, mode="rich")
+    x = synthetic_images(2, cfg, seed=5).double()
+    tok = vo.forward(x, sd, cfg, keep=True)["tokens"]
+    g = torch.Generator().manual_seed(0)
+    off = torch.randn(cfg.dim, generator=g, dtype=torch.float64) * 2.0            # a channel-constant offset on every row
+    rows = tok + off
+    plain = vo.encoder_layer(rows, sd, 0, cfg)
+    saved = (vo.ROUND_ONLY, vo.LN_FOLD, vo.LN_CENTRE)
+    try:
+        vo.LN_FOLD = True
+        vo.LN_CENTRE = torch.randn(2 * cfg.layers, cfg.dim, generator=g) * 3.0   # arbitrary vectors
+        vo.ROUND_ONLY = frozenset()
+        emu = vo.encoder_layer(rows, sd, 0, cfg, emulate=True)
+        assert float((plain - emu).abs().max() / plain.abs().max()) <= 1e-5
+        vo.ROUND_ONLY = None
+        vo.LN_CENTRE = None
+        e_plain_copy = float((plain - vo.encoder_layer(rows, sd, 0, cfg, emulate=True)).abs().max() / plain.abs().max())
+        m = rows.reshape(-1, cfg.dim).mean(0).float()                             # what the calibration takes: the per-channel means
+        vo.LN_CENTRE = torch.stack([m] * (2 * cfg.layers))
+        e_centred = float((plain - vo.encoder_layer(rows, sd, 0, cfg, emulate=True)).abs().max() / plain.abs().max())
+        assert e_centred < e_plain_copy, (e_centred, e_plain_copy)
+    finally:
+        vo.ROUND_ONLY, vo.LN_FOLD, vo.LN_CENTRE = saved
+
+
 def test_seeded_weights_and_image_are_pinned():
     cfg = VARIANTS[VGOLD["config"]]
     sd = init_weights(cfg, seed=VGOLD["weights"]["seed"], mode=VGOLD["weights"]["mode"])
