@@ -14,7 +14,9 @@ if [ "$1" != "gemm" ]; then
     hipcc $F -DATTN_BENCH_OWN_LDS_HELPER attn_bench.hip $C/kernels_attn.hip -o attn_bench.bin &
     hipcc $F fused_bench.hip $C/kernels_gemm.hip $C/kernels_attn.hip -o fused_bench.bin &
     # the whole engine with every study variant compiled in (IVIT_LIB=tools/libivit_abl.so python bench.py ...: in-situ A/B through the env knobs of kernels_gemm.hip)
-    hipcc $F -fPIC -shared $C/engine.hip $C/kernels_gemm.hip $C/kernels_attn.hip $C/kernels_misc.hip -o libivit_abl.so -Wl,-rpath,/opt/rocm/lib &
+    hipcc $F -fPIC -shared $C/engine.hip $C/kernels_gemm.hip $C/kernels_attn.hip $C/kernels_misc.hip $C/kernels_mlp.hip -o libivit_abl.so -Wl,-rpath,/opt/rocm/lib &
+    # fused MLP kernel against the two GEMM launches, bitwise + timing + per-workgroup stamps / ablations (links the product library: build it first)
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 mlp_fused_bench.hip -L../interactive_vit_amd -livit -Wl,-rpath,'$ORIGIN/../interactive_vit_amd' -o mlp_fused_bench.bin &
     for probe in mfma_peak mfma_pattern mfma_f8_probe permlane_probe dma_l1_probe simd_share_probe; do   # single-file hardware probes
         [ -f $probe.bin ] && [ $probe.bin -nt $probe.hip ] || hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-unused-result $probe.hip -o $probe.bin
     done
