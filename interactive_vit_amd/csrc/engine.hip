@@ -239,6 +239,7 @@ struct ivit_engine {
     // LayerNorm fold (bf16 data path; IVIT_FOLD_LN=0 keeps the LayerNorm kernel): see run_layer
     uint64_t stats_token = 0; int stats_batch = 0;   // resident_token of the host-call output whose LayerNorm statistics pairs / 16-bit copy are in the workspace
     bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
+    bool gemm_tail = true;          // peel the rows of a nearly empty last round of 256 x 256 tiles into their own launch (kernels_gemm.hip: gemm_tail_rows; IVIT_GEMM_TAIL=0: off)
     int gemm_group_n = 0;           // study knob IVIT_GEMM_GROUP_N (>= 3): column-panel width of the 256 x 256 tiles' block -> tile map (default 8: gemm_kernel.h: GEMM_GROUP_N)
     bool fused_mlp = false;         // LN2 -> MLP up -> GELU -> MLP down -> residual in ONE launch where the shape allows (IVIT_FUSED_MLP=0 switches it off)
     // Centred operand copy (round 5): one calibrated per-channel vector per LayerNorm input - site 2 i = LN1 of layer i, 2 i + 1 = LN2 - subtracted before the
@@ -416,6 +417,8 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         const char* fl = getenv("IVIT_FOLD_LN");
         e->fold_ln = !(fl && atoi(fl) == 0) && !precision_is_fp8(cfg->precision) && cfg->dim <= 64 * GEMM_LN_SLOTS;
         e->fold_always = fl && atoi(fl) == 2;
+        const char* gt = getenv("IVIT_GEMM_TAIL");
+        e->gemm_tail = !(gt && atoi(gt) == 0);
         const char* gg = getenv("IVIT_GEMM_GROUP_N");
         e->gemm_group_n = gg && atoi(gg) >= 3 ? atoi(gg) : 0;
         const char* fc = getenv("IVIT_FOLD_CENTRE");
@@ -690,6 +693,15 @@ static int run_gemm(ivit_engine* e, hipStream_t st, const bf16_t* A, int lda, co
     const double flops = 2.0 * M * (double)W.rows * W.cols;
     const double bytes = 2.0 * ((double)M * W.cols + (double)W.rows * W.cols) + (double)M * W.rows * (bf_out ? 2 : 4) +
                          (resid_in ? 4.0 * M * W.rows : 0.0) + (stats_out ? 2.0 * M * W.rows : 0.0);
+    const int tail = e->gemm_tail ? gemm_tail_rows(p, false) : 0;
+    if (tail) {   // the rows of the grid's nearly empty last round go out as a launch of their own on the small-grid tiles (kernels_gemm.hip: gemm_tail_rows)
+        GemmParams head = p; head.M = M - tail;
+        const GemmParams rest = gemm_rows_from(p, M - tail, false);
+        const double share = (double)tail / M;
+        { ProfScope ps(e, PC_GEMM, st, flops * (1.0 - share), bytes * (1.0 - share), role, gemm_kernel_name(head)); HIP_TRY(launch_gemm(head, st)); }
+        { ProfScope ps(e, PC_GEMM, st, flops * share, bytes * share, role, gemm_kernel_name(rest)); HIP_TRY(launch_gemm(rest, st)); }
+        return 0;
+    }
     ProfScope ps(e, PC_GEMM, st, flops, bytes, role, gemm_kernel_name(p));
     HIP_TRY(launch_gemm(p, st));
     return 0;
@@ -717,6 +729,15 @@ static int run_gemm_fp8(ivit_engine* e, hipStream_t st, const unsigned char* A, 
     const double out_b = (epi == EPI_BIAS_GELU_FP8) ? 1.0 : (epi == EPI_BIAS_BF16 ? 2.0 : 4.0);
     const double bytes = ((double)M * q.cols + (double)q.rows * q.cols) + (double)M * q.rows * out_b +
                          (epi == EPI_BIAS_RESID_F32 ? 4.0 * M * q.rows : 0.0);
+    const int tail = e->gemm_tail ? gemm_tail_rows(p, true) : 0;
+    if (tail) {
+        GemmParams head = p; head.M = M - tail;
+        const GemmParams rest = gemm_rows_from(p, M - tail, true);
+        const double share = (double)tail / M;
+        { ProfScope ps(e, PC_GEMM, st, flops * (1.0 - share), bytes * (1.0 - share), role, gemm_fp8_kernel_name(head)); HIP_TRY(launch_gemm_fp8(head, st)); }
+        { ProfScope ps(e, PC_GEMM, st, flops * share, bytes * share, role, gemm_fp8_kernel_name(rest)); HIP_TRY(launch_gemm_fp8(rest, st)); }
+        return 0;
+    }
     ProfScope ps(e, PC_GEMM, st, flops, bytes, role, gemm_fp8_kernel_name(p));
     HIP_TRY(launch_gemm_fp8(p, st));
     return 0;

@@ -78,6 +78,8 @@ hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);                       // picks the tile
 hipError_t launch_gemm_variant(const GemmParams& p, int variant, hipStream_t stream);
 int gemm_pick_variant(int M, int N, int K);
+int gemm_tail_rows(const GemmParams& p, bool fp8);                      // rows to peel off the end of M so that the 256 x 256 grid does not end on a nearly empty round (0: none)
+GemmParams gemm_rows_from(const GemmParams& p, int m_off, bool fp8);   // the same launch for rows m_off .. M
 bool gemm_prefers_256(int M, int N, int K);   // the one-workgroup-per-CU 256x256 tile is picked (many rounds of tiles)
 const char* gemm_variant_name(int v);
 // name of the kernel launch_gemm / launch_gemm_fp8 dispatches for these parameters (per-kernel profiling, dispatch tests)

@@ -546,4 +546,44 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
     return launch_gemm_variant(p, gemm_pick_variant(p.M, p.N, p.K), stream);
 }
 
+// Tail split (round 5).  A grid of one-per-CU 256 x 256 tiles runs in rounds of `cus` tiles; when the tile count is a few over a multiple of that, the last
+// round is a handful of tiles on an otherwise idle chip - ViT-H/14 at B = 256 has 257 row tiles, so EVERY encoder GEMM ends on a round of 5 ... 20 tiles (out-
+// projection / MLP down: 5.02 rounds - a sixth of the launch).  Returns how many rows to peel off the END of M so that what is left runs without that round; the
+// caller launches the peeled rows (whole row tiles, so at most a few hundred rows) separately through the dispatcher, which gives them the small-grid tiles -
+// same K order, bit-identical outputs.  0 = leave the launch alone (not the 256 x 256 tile, a row remap, fewer than three rounds, or a last round more than an
+// eighth full).
+// Measured in the ViT-H/14 B = 256 forward (same box, alternating; profiles/r05_tail_split.txt): MLP down (K = 5120, f32 residual epilogue) 824 -> 762 us, out-
+// projection 322 -> 308, MLP up 837 -> 830, QKV 587 -> 591 (a last round of 15 tiles on an idle chip is cheaper than a launch of small tiles when K is short and
+// the epilogue light) - so only the residual-epilogue GEMMs and deep K are split; the e4m3 GEMMs not at all (their small-grid tile, 128 x 128 on one stage, is slow
+// alone on a CU: no gain on any of the four).
+int gemm_tail_rows(const GemmParams& p, bool fp8) {
+    if (fp8 || p.grp_in > 0 || p.M <= 0 || p.N <= 0) return 0;
+    if (gemm_family(p.epi) != 3 && gemm_family(p.epi) != 1 && p.K < 2048) return 0;
+    const bool t256 = fp8 ? fp8_tile(p) == GEMM_TILE_256S : gemm_pick_variant(p.M, p.N, p.K) == GEMM_TILE_256S;
+    if (!t256) return 0;
+    const int cus = device_cu_count();
+    const int tm = ceil_div(p.M, 256), tn = ceil_div(p.N, 256), tiles = tm * tn, rem = tiles % cus;
+    if (tiles < 3 * cus || rem == 0 || rem * 8 > cus) return 0;
+    const int r = ceil_div(rem, tn);
+    if (r >= tm) return 0;
+    GemmParams q = p; q.M = (tm - r) * 256;
+    if (!(fp8 ? fp8_tile(q) == GEMM_TILE_256S : gemm_pick_variant(q.M, q.N, q.K) == GEMM_TILE_256S)) return 0;
+    return p.M - q.M;
+}
+
+// p advanced by m_off rows (every per-row pointer of the launch; fp8: A is a byte matrix)
+GemmParams gemm_rows_from(const GemmParams& p, int m_off, bool fp8) {
+    GemmParams t = p;
+    t.M = p.M - m_off;
+    t.A = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(p.A) + (size_t)m_off * p.lda * (fp8 ? 1 : 2));
+    const int fam = gemm_family(p.epi);
+    const size_t osz = fam == 3 || fam == 1 ? 4 : (p.epi == EPI_BIAS_GELU_FP8 ? 1 : 2);
+    t.out = reinterpret_cast<char*>(p.out) + (size_t)m_off * p.ldo * osz;
+    if (p.resid) t.resid = p.resid + (size_t)m_off * p.ldr;
+    if (p.xb) t.xb = p.xb + (size_t)m_off * p.ldxb;
+    if (p.ln_part) t.ln_part = p.ln_part + (size_t)m_off * GEMM_LN_SLOTS;
+    if (p.ln_stats) t.ln_stats = p.ln_stats + m_off;
+    return t;
+}
+
 }  // namespace ivit
