@@ -557,13 +557,14 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
 // the epilogue light) - so only the residual-epilogue GEMMs and deep K are split; the e4m3 GEMMs not at all (their small-grid tile, 128 x 128 on one stage, is slow
 // alone on a CU: no gain on any of the four).
 int gemm_tail_rows(const GemmParams& p, bool fp8) {
+    static const int wide = [] { const char* v = getenv("IVIT_GEMM_TAIL"); return v ? atoi(v) : 1; }();   // study knob: 2 = also last rounds up to 60 % full, every epilogue family
     if (fp8 || p.grp_in > 0 || p.M <= 0 || p.N <= 0) return 0;
-    if (gemm_family(p.epi) != 3 && gemm_family(p.epi) != 1 && p.K < 2048) return 0;
+    if (wide < 2 && gemm_family(p.epi) != 3 && gemm_family(p.epi) != 1 && p.K < 2048 && p.N < 4 * p.K) return 0;   // (N >= 4 K: MLP up - ViT-L/16-384 B = 128 662 -> 648 us, ViT-H 846 -> 839)
     const bool t256 = fp8 ? fp8_tile(p) == GEMM_TILE_256S : gemm_pick_variant(p.M, p.N, p.K) == GEMM_TILE_256S;
     if (!t256) return 0;
     const int cus = device_cu_count();
     const int tm = ceil_div(p.M, 256), tn = ceil_div(p.N, 256), tiles = tm * tn, rem = tiles % cus;
-    if (tiles < 3 * cus || rem == 0 || rem * 8 > cus) return 0;
+    if (tiles < 3 * cus || rem == 0 || (wide >= 2 ? rem * 10 > cus * 6 : rem * 8 > cus)) return 0;
     const int r = ceil_div(rem, tn);
     if (r >= tm) return 0;
     GemmParams q = p; q.M = (tm - r) * 256;
