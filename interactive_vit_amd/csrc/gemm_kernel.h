@@ -1080,7 +1080,7 @@ struct GemmTileDeep : GemmTile<WAVES_M_, WAVES_N_, FM_, FN_> {
     static_assert(Base::A_PIECES % Base::WAVES == 0 && Base::W_PIECES % Base::WAVES == 0, "every wave must issue the same number of DMA pieces");
 };
 
-template <class T, int EK = 0, class OP = OpBf16>
+template <class T, int EK = 0, class OP = OpBf16, bool FP8 = false>
 __device__ __forceinline__ void gemm_body_deep(const GemmParams& p, char* smem) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1092,8 +1092,10 @@ __device__ __forceinline__ void gemm_body_deep(const GemmParams& p, char* smem) 
     f32x4 acc[T::FM][T::FN];
     gemm_acc_init<T, EK>(p, acc, n0 + wc * T::FN * 16, (threadIdx.x & 63) >> 4);
 
-    const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
-    const int nt = p.K / GEMM_BK, last = nt - 1;
+    // a K-tile is 128 BYTES of every row: 64 bf16 / f16 or 128 e4m3 (round 5: the tail rows of the e4m3 256 x 256 grids)
+    constexpr int ESZ = FP8 ? 1 : 2;
+    const size_t lda_b = (size_t)p.lda * ESZ, ldw_b = (size_t)p.ldw * ESZ;
+    const int nt = p.K * ESZ / 128, last = nt - 1;
     float2* tile_stats = reinterpret_cast<float2*>(smem + T::LDS_BYTES);   // EK == 2 kernels are launched with BM * 8 more bytes
     if (EK == 2) {
         ln_tile_stats<T>(p, m0, tile_stats);   // ordinary loads: before any DMA is in flight
@@ -1117,6 +1119,20 @@ __device__ __forceinline__ void gemm_body_deep(const GemmParams& p, char* smem) 
         stage(t + T::STAGES - 1, slot == 0 ? T::STAGES - 1 : slot - 1);
         const char* a_tile = smem + slot * T::STAGE_BYTES;
         const char* w_tile = a_tile + T::A_BYTES;
+        if (FP8) {   // one 128-deep scaled MFMA per fragment pair and K-tile (see gemm_body)
+            bf16x8 af[T::FM][2], wf[T::FN][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) wf[j][kk] = read_frag(w_tile, (wc * T::FN + j) * 16 + fr, kk * 4 + fq);
+#pragma unroll
+                for (int i = 0; i < T::FM; ++i) af[i][kk] = read_frag(a_tile, (wr * T::FM + i) * 16 + fr, kk * 4 + fq);
+            }
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) acc[i][j] = mfma_e4m3_16x16x128(wf[j], af[i], acc[i][j]);
+        } else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 af[T::FM], wf[T::FN];

@@ -109,6 +109,15 @@ IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep, 0, OpF16)
 IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_rs, 1, OpF16)
 IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_lf, 2, OpF16)
 #undef IVIT_DEEP_KERNEL
+// e4m3 operands on the same ring (round 5): the tail rows of the e4m3 256 x 256 grids (gemm_tail_rows)
+#define IVIT_DEEP8_KERNEL(NAME, EK)                                                          \
+    __global__ __launch_bounds__(Tile64D::THREADS, 1) void NAME(GemmParams p) {              \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                          \
+        gemm_body_deep<Tile64D, EK, OpBf16, true>(p, smem);                                   \
+    }
+IVIT_DEEP8_KERNEL(ivit_gemm_fp8_64x128x128_deep, 0)
+IVIT_DEEP8_KERNEL(ivit_gemm_fp8_64x128x128_deep_f32, 3)
+#undef IVIT_DEEP8_KERNEL
 
 #ifdef IVIT_GEMM_ABLATIONS   // microbenchmark-only builds (tools/gemm_bench): the variants that lost, and timing ablations
 // the two-stage form of the 128 x 128 tile (the 160 x 128 one is a product kernel; it is the bit-identity reference of tools/gemm_bench)
@@ -499,6 +508,9 @@ hipError_t launch_gemm_variant(const GemmParams& p_in, int variant, hipStream_t 
 
 // fp8 operands: the three-per-CU tiles or the 256 x 256 staggered tile, under the 16-bit rule (no deep-ring form: small fp8 grids take 160 x 128)
 static int fp8_tile(const GemmParams& p) {
+    // a grid that fits one round of 64 x 128 tiles, one workgroup per CU, AND is deep (K >= 2048 bytes): the deep-ring tile - the peeled tail rows of the 256 x 256
+    // grids (gemm_tail_rows); the single-stage tiles pay a DMA round trip per K-tile when they are alone on a CU
+    if (p.K >= 2048 && p.M <= 512 && ceil_div(p.M, Tile64D::BM) * ceil_div(p.N, Tile64D::BN) <= 256) return GEMM_TILE_64D;
     // the square out-projection (N = K = D, f32 residual epilogue) on three 160 x 128 workgroups per CU: 226.7 against 232.3 us at ViT-H/14 B = 256
     // (its read-modify-write burst is exposed at one workgroup per CU; round 4, in the forward: 3 865 -> 3 888 img/s)
     if (p.N == p.K && p.epi == EPI_BIAS_RESID_F32 && ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) >= 256) return GEMM_TILE_160SB;
@@ -511,6 +523,7 @@ const char* gemm_fp8_kernel_name(const GemmParams& p) {
     switch (fp8_tile(p)) {
         case GEMM_TILE_256S: return f32 ? "ivit_gemm_fp8_256x256x128_stag_f32" : "ivit_gemm_fp8_256x256x128_stag";
         case GEMM_TILE_160SB: return f32 ? "ivit_gemm_fp8_160x128x128_sb_f32" : "ivit_gemm_fp8_160x128x128_sb";
+        case GEMM_TILE_64D: return f32 ? "ivit_gemm_fp8_64x128x128_deep_f32" : "ivit_gemm_fp8_64x128x128_deep";
     }
     return f32 ? "ivit_gemm_fp8_128x128x128_sb_f32" : "ivit_gemm_fp8_128x128x128_sb";
 }
@@ -538,6 +551,7 @@ hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
     switch (fp8_tile(p)) {
         case GEMM_TILE_256S: return f32 ? launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag_f32, p, stream) : launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag, p, stream);
         case GEMM_TILE_160SB: return f32 ? launch_sb<Tile160>(ivit_gemm_fp8_160x128x128_sb_f32, p, stream) : launch_sb<Tile160>(ivit_gemm_fp8_160x128x128_sb, p, stream);
+        case GEMM_TILE_64D: return f32 ? launch_tile<Tile64D>(ivit_gemm_fp8_64x128x128_deep_f32, p, stream) : launch_tile<Tile64D>(ivit_gemm_fp8_64x128x128_deep, p, stream);
     }
     return f32 ? launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb_f32, p, stream) : launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb, p, stream);
 }
@@ -554,11 +568,12 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
 // eighth full).
 // Measured in the ViT-H/14 B = 256 forward (same box, alternating; profiles/r05_tail_split.txt): MLP down (K = 5120, f32 residual epilogue) 824 -> 762 us, out-
 // projection 322 -> 308, MLP up 837 -> 830, QKV 587 -> 591 (a last round of 15 tiles on an idle chip is cheaper than a launch of small tiles when K is short and
-// the epilogue light) - so only the residual-epilogue GEMMs and deep K are split; the e4m3 GEMMs not at all (their small-grid tile, 128 x 128 on one stage, is slow
-// alone on a CU: no gain on any of the four).
+// the epilogue light) - so only the residual-epilogue GEMMs, deep K and MLP up are split; of the e4m3 GEMMs only MLP down (K = 5120), on the e4m3 deep-ring tile
+// (463 -> 443 us; with the single-stage 128 x 128 tile, slow alone on a CU, none of the four gained).
 int gemm_tail_rows(const GemmParams& p, bool fp8) {
     static const int wide = [] { const char* v = getenv("IVIT_GEMM_TAIL"); return v ? atoi(v) : 1; }();   // study knob: 2 = also last rounds up to 60 % full, every epilogue family
-    if (fp8 || p.grp_in > 0 || p.M <= 0 || p.N <= 0) return 0;
+    static const int tail8 = [] { const char* v = getenv("IVIT_GEMM_TAIL_FP8"); return v ? atoi(v) : 1; }();
+    if ((fp8 && (!tail8 || p.K < 2048)) || p.grp_in > 0 || p.M <= 0 || p.N <= 0) return 0;
     if (wide < 2 && gemm_family(p.epi) != 3 && gemm_family(p.epi) != 1 && p.K < 2048 && p.N < 4 * p.K) return 0;   // (N >= 4 K: MLP up - ViT-L/16-384 B = 128 662 -> 648 us, ViT-H 846 -> 839)
     const bool t256 = fp8 ? fp8_tile(p) == GEMM_TILE_256S : gemm_pick_variant(p.M, p.N, p.K) == GEMM_TILE_256S;
     if (!t256) return 0;

@@ -13,8 +13,8 @@ PY
 }
 B="timeout -k 10 400 python bench.py --no-cpu-baseline --no-tolerance-mode --no-layernorm-leg --steps 10 --warmup 3"
 for i in 1 2; do
-  run h14_bf16_tail_$i $B --model vit_h_14 --batch-per-gpu 256 --precision bf16 || exit 1
-  run h14_bf16_off_$i IVIT_GEMM_TAIL=0 $B --model vit_h_14 --batch-per-gpu 256 --precision bf16 || exit 1
+
+
   run c5_fp8_tail_$i $B --config 5 || exit 1
-  run c5_fp8_off_$i IVIT_GEMM_TAIL=0 $B --config 5 || exit 1
+  run c5_fp8_off_$i IVIT_GEMM_TAIL_FP8=0 $B --config 5 || exit 1
 done
