@@ -115,7 +115,6 @@ IVIT_DEEP_KERNEL(ivit_gemm_f16_64x128x64_deep_lf, 2, OpF16)
         extern __shared__ __attribute__((aligned(16))) char smem[];                          \
         gemm_body_deep<Tile64D, EK, OpBf16, true>(p, smem);                                   \
     }
-IVIT_DEEP8_KERNEL(ivit_gemm_fp8_64x128x128_deep, 0)
 IVIT_DEEP8_KERNEL(ivit_gemm_fp8_64x128x128_deep_f32, 3)
 #undef IVIT_DEEP8_KERNEL
 
@@ -510,7 +509,8 @@ hipError_t launch_gemm_variant(const GemmParams& p_in, int variant, hipStream_t 
 static int fp8_tile(const GemmParams& p) {
     // a grid that fits one round of 64 x 128 tiles, one workgroup per CU, AND is deep (K >= 2048 bytes): the deep-ring tile - the peeled tail rows of the 256 x 256
     // grids (gemm_tail_rows); the single-stage tiles pay a DMA round trip per K-tile when they are alone on a CU
-    if (p.K >= 2048 && p.M <= 512 && ceil_div(p.M, Tile64D::BM) * ceil_div(p.N, Tile64D::BN) <= 256) return GEMM_TILE_64D;
+    // (f32-output epilogues only: the one e4m3 GEMM of a ViT with K >= 2048 is MLP down)
+    if (gemm_family(p.epi) == 3 && p.K >= 2048 && p.M <= 512 && ceil_div(p.M, Tile64D::BM) * ceil_div(p.N, Tile64D::BN) <= 256) return GEMM_TILE_64D;
     // the square out-projection (N = K = D, f32 residual epilogue) on three 160 x 128 workgroups per CU: 226.7 against 232.3 us at ViT-H/14 B = 256
     // (its read-modify-write burst is exposed at one workgroup per CU; round 4, in the forward: 3 865 -> 3 888 img/s)
     if (p.N == p.K && p.epi == EPI_BIAS_RESID_F32 && ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) >= 256) return GEMM_TILE_160SB;
@@ -523,7 +523,7 @@ const char* gemm_fp8_kernel_name(const GemmParams& p) {
     switch (fp8_tile(p)) {
         case GEMM_TILE_256S: return f32 ? "ivit_gemm_fp8_256x256x128_stag_f32" : "ivit_gemm_fp8_256x256x128_stag";
         case GEMM_TILE_160SB: return f32 ? "ivit_gemm_fp8_160x128x128_sb_f32" : "ivit_gemm_fp8_160x128x128_sb";
-        case GEMM_TILE_64D: return f32 ? "ivit_gemm_fp8_64x128x128_deep_f32" : "ivit_gemm_fp8_64x128x128_deep";
+        case GEMM_TILE_64D: return "ivit_gemm_fp8_64x128x128_deep_f32";
     }
     return f32 ? "ivit_gemm_fp8_128x128x128_sb_f32" : "ivit_gemm_fp8_128x128x128_sb";
 }
@@ -551,7 +551,7 @@ hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
     switch (fp8_tile(p)) {
         case GEMM_TILE_256S: return f32 ? launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag_f32, p, stream) : launch_tile<Tile256P>(ivit_gemm_fp8_256x256x128_stag, p, stream);
         case GEMM_TILE_160SB: return f32 ? launch_sb<Tile160>(ivit_gemm_fp8_160x128x128_sb_f32, p, stream) : launch_sb<Tile160>(ivit_gemm_fp8_160x128x128_sb, p, stream);
-        case GEMM_TILE_64D: return f32 ? launch_tile<Tile64D>(ivit_gemm_fp8_64x128x128_deep_f32, p, stream) : launch_tile<Tile64D>(ivit_gemm_fp8_64x128x128_deep, p, stream);
+        case GEMM_TILE_64D: return launch_tile<Tile64D>(ivit_gemm_fp8_64x128x128_deep_f32, p, stream);
     }
     return f32 ? launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb_f32, p, stream) : launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb, p, stream);
 }
