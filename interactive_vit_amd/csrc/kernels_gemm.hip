@@ -514,6 +514,13 @@ static int fp8_tile(const GemmParams& p) {
     // the square out-projection (N = K = D, f32 residual epilogue) on three 160 x 128 workgroups per CU: 226.7 against 232.3 us at ViT-H/14 B = 256
     // (its read-modify-write burst is exposed at one workgroup per CU; round 4, in the forward: 3 865 -> 3 888 img/s)
     if (p.N == p.K && p.epi == EPI_BIAS_RESID_F32 && ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) >= 256) return GEMM_TILE_160SB;
+    // MLP up (GELU + e4m3 quantisation in the epilogue) on three 160 x 128 workgroups per CU as well: with the MFMA time halved that epilogue is a quarter of a
+    // 256 x 256 tile's life and nothing hides it at one workgroup per CU.  ViT-H/14 B = 256 in the forward, same box, alternating (round 5, IVIT_FP8_160 = bit mask:
+    // 1 MLP up, 2 QKV, 4 MLP down):  0: 3 960 / 3 971 img/s (MLP up 597 us);  1: 4 118 / 4 095 (521 us; +3.6 %);  3: 4 100 / 4 085 (QKV 341 -> 373 us);
+    // 5: 3 926 / 3 917 (MLP down 441 -> 527 us)
+    static const int m160 = [] { const char* v = getenv("IVIT_FP8_160"); return v ? atoi(v) : 1; }();
+    if (ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) >= 256 &&
+        (((m160 & 1) && p.epi == EPI_BIAS_GELU_FP8) || ((m160 & 2) && p.epi == EPI_BIAS_BF16) || ((m160 & 4) && p.epi == EPI_BIAS_RESID_F32))) return GEMM_TILE_160SB;
     if (gemm_prefers_256(p.M, p.N, p.K)) return GEMM_TILE_256S;
     return ceil_div(p.M, Tile160::BM) * ceil_div(p.N, Tile160::BN) >= 256 ? GEMM_TILE_160SB : GEMM_TILE_128SB;
 }
