@@ -106,10 +106,12 @@ int ivit_set_weight(ivit_engine* e, const char* name, const float* host, const i
 int ivit_weights_ready(ivit_engine* e);
 
 /* 1 when a forward of `batch` images folds every LayerNorm of the encoder into the GEMM that consumes it, else 0.
- * The fold is the default on the bf16 data path (IVIT_FOLD_LN=0 in the environment at ivit_create disables it) for
- * calls whose residual GEMMs run two workgroups per CU; calls large enough for the 256x256 tile keep the LayerNorm
- * kernel.  Both forms are bf16 evaluations of the same f32 contract with different rounding points; the parity tests
- * ask which one the oracle's rounding-aware mode has to mirror. */
+ * The fold is the default on the 16-bit data paths (IVIT_FOLD_LN=0 in the environment at ivit_create disables it) at every
+ * batch size since round 5 (calls large enough for the one-per-CU 256x256 tile - ViT-L / ViT-H batches - fold the row
+ * statistics once per row with a small kernel; IVIT_FOLD_LN=3 restores rounds 3-4's rule, which kept the LayerNorm kernels
+ * there); the e4m3 paths and a weight set that trips the guard (ivit_ln_fold_calibrate) keep the kernels.  Both forms are
+ * 16-bit evaluations of the same f32 contract with different rounding points; the parity tests ask which one the oracle's
+ * rounding-aware mode has to mirror. */
 int ivit_ln_fold(const ivit_engine* e, int batch);
 
 /* 0 when the MLP of a forward of `batch` images runs as two GEMM launches (MLP up + GELU, MLP down + residual); else the form of the fused MLP

@@ -183,6 +183,7 @@ struct Ws {
     float *x, *clsf;
     unsigned char *h8, *att8, *u8;   // fp8 data path only
     float2* ln_part;                 // LayerNorm fold: per-row, per-64-column (sum, M2) pairs
+    float2* ln_stats;                // ... and, where a small kernel folds them once per row (launch_ln_finalize), the finished (mean, rstd)
 };
 
 struct ivit_engine {
@@ -238,7 +239,7 @@ struct ivit_engine {
     bool graphs_on = true;
     // LayerNorm fold (bf16 data path; IVIT_FOLD_LN=0 keeps the LayerNorm kernel): see run_layer
     uint64_t stats_token = 0; int stats_batch = 0;   // resident_token of the host-call output whose LayerNorm statistics pairs / 16-bit copy are in the workspace
-    bool fold_ln = false, fold_ready = false, fold_always = false;   // fold_always: IVIT_FOLD_LN=2 (measurement knob)
+    bool fold_ln = false, fold_ready = false, fold_small_only = false;   // fold_small_only: IVIT_FOLD_LN=3 (measurement knob: rounds 3-4's rule)
     bool gemm_tail = true;          // peel the rows of a nearly empty last round of 256 x 256 tiles into their own launch (kernels_gemm.hip: gemm_tail_rows; IVIT_GEMM_TAIL=0: off)
     int gemm_group_n = 0;           // study knob IVIT_GEMM_GROUP_N (>= 3): column-panel width of the 256 x 256 tiles' block -> tile map (default 8: gemm_kernel.h: GEMM_GROUP_N)
     bool fused_mlp = false;         // LN2 -> MLP up -> GELU -> MLP down -> residual in ONE launch where the shape allows (IVIT_FUSED_MLP=0 switches it off)
@@ -258,6 +259,7 @@ struct ivit_engine {
     float* ratio_scratch = nullptr; // its device word, allocated once at ivit_create
     bool ratio_on = false;
     float2* ln_part = nullptr;
+    float2* ln_stats = nullptr;
     int graph_max_batch = 4;
     std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;   // (begin, end, batch, which buffer is the input)
     // chained host calls: the f32 output of the last host call stays in ext_out; a call that presents that
@@ -416,7 +418,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
         e->graphs_on = !(gr && atoi(gr) == 0);
         const char* fl = getenv("IVIT_FOLD_LN");
         e->fold_ln = !(fl && atoi(fl) == 0) && !precision_is_fp8(cfg->precision) && cfg->dim <= 64 * GEMM_LN_SLOTS;
-        e->fold_always = fl && atoi(fl) == 2;
+        e->fold_small_only = fl && atoi(fl) == 3;
         const char* gt = getenv("IVIT_GEMM_TAIL");
         e->gemm_tail = !(gt && atoi(gt) == 0);
         const char* gg = getenv("IVIT_GEMM_GROUP_N");
@@ -472,6 +474,7 @@ extern "C" int ivit_create(const ivit_config* cfg, ivit_engine** out) {
     chk(dev_alloc(e, (void**)&e->u, (size_t)rows_tok * Mlp * 2, true));
     chk(dev_alloc(e, (void**)&e->hc, (size_t)(round_up(B, 256) + 256) * e->ld_hc * 2, true));
     chk(dev_alloc(e, (void**)&e->ln_part, (size_t)rows_tok * GEMM_LN_SLOTS * sizeof(float2), true));
+    chk(dev_alloc(e, (void**)&e->ln_stats, (size_t)rows_tok * sizeof(float2), true));
     if (precision_is_fp8(cfg->precision)) {
         e->ld8d = round_up(D, 128); e->ld8m = round_up(Mlp, 128);
         chk(dev_alloc(e, (void**)&e->h8, (size_t)rows_tok * e->ld8d, true));
@@ -806,13 +809,16 @@ static int run_layer_fp8m(ivit_engine* e, const Ws& w, hipStream_t st, int li, i
     return run_gemm_fp8(e, st, w.u8, e->ld8m, lw.q2, M, lw.b2, EPI_BIAS_RESID_F32, xo, D, w.x, D, 1.0f, "mlp2");
 }
 
-// The LayerNorm fold pays where the residual GEMMs run two workgroups per CU (their longer epilogue hides behind
-// the other workgroup's main loop: ViT-B/16 +3.5 %); where they take the 256x256 tile (ViT-L / ViT-H batches, one
-// workgroup per CU) the exposed epilogue costs more than the LayerNorm kernels it saves (-1...-2 %), so those calls
-// keep the LayerNorm kernel.  Same weights, decided per call from the token-row count.
+// The LayerNorm fold on every 16-bit call (round 5).  Rounds 3-4 kept the LayerNorm kernels where the residual GEMMs take the one-per-CU 256 x 256 tile (ViT-L /
+// ViT-H batches): the exposed _rs epilogue cost as much as the kernels it saved.  What really cost there was the consumers folding the same statistics pairs at the
+// start of EVERY column tile (12 - 20 per row block: 35 - 50 us per GEMM); with the pairs folded once per row by a small kernel (fold_finalize_for_rows,
+// launch_ln_finalize) the fold wins there too: ViT-L/16-384 B = 128 2 385 ... 2 402 -> 2 456 ... 2 470 img/s, ViT-H/14 B = 256 2 831 -> 2 888 (same box).
+// IVIT_FOLD_LN=3 restores the old rule (A/B).
 static bool fold_for_rows(const ivit_engine* e, int M) {
-    return e->fold_ln && !e->fold_blocked && (e->fold_always || !gemm_prefers_256(M, e->D, e->D));
+    return e->fold_ln && !e->fold_blocked && (!e->fold_small_only || !gemm_prefers_256(M, e->D, e->D));
 }
+// ... with the statistics finalised by a kernel where the QKV / MLP-up grids are many column tiles of 256 wide
+static bool fold_finalize_for_rows(const ivit_engine* e, int M) { return gemm_prefers_256(M, e->D, e->D); }
 
 // The fused MLP kernel runs one workgroup of 64 rows per CU: it takes the calls whose grids fill at least 70 % of the CU slots of their last round
 // (ViT-B/16: B = 64 -> 197 workgroups, B = 256 -> 788 = 3.08 rounds); below that - the interactive path - the GEMM pair on its small tiles is faster.
@@ -867,6 +873,14 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
             HIP_TRY(launch_row_stats(xi, D, M, D, w.h, D, w.ln_part, st, e->f16, 1, site_centre(e, 2 * li)));
         }
         if (tap == TAP_H1) return 0;
+        // consumers on the 256 x 256 tile with many column tiles (ViT-L / ViT-H): the pairs are folded ONCE per row by a small kernel instead of at the start of
+        // every column tile (12 - 20 times per row block)
+        const bool finalize = fold_finalize_for_rows(e, M);
+        if (finalize) {
+            ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * (8.0 * (D / 64) + 8.0));
+            HIP_TRY(launch_ln_finalize(w.ln_part, M, D, e->cfg.ln_eps, w.ln_stats, st));
+            fold.stats = w.ln_stats;
+        }
         fold.s = lw.s_in; fold.d = site_centre(e, 2 * li) ? lw.d_in : nullptr;
         if (run_gemm(e, st, w.h, D, lw.wf_in, M, lw.c_in, EPI_LNFOLD_BF16, w.qkv, 3 * D, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "qkv")) return 1;
         if (tap == TAP_QKV) return 0;
@@ -875,6 +889,10 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         fold.centre = site_centre(e, 2 * li + 1);   // the copy of the new rows is LN2's operand
         if (run_gemm(e, st, w.att, e->ld_att, lw.w_out, M, lw.b_out, EPI_BIAS_RESID_STATS, w.x, D, xi, D, nullptr, 0, 0, 0, 0, &fold, "proj")) return 1;
         if (tap == TAP_PROJ || tap == TAP_H2) return 0;
+        if (finalize) {
+            ProfScope ps(e, PC_LAYERNORM, st, 0.0, (double)M * (8.0 * (D / 64) + 8.0));
+            HIP_TRY(launch_ln_finalize(w.ln_part, M, D, e->cfg.ln_eps, w.ln_stats, st));
+        }
         fold.s = lw.s_1; fold.d = site_centre(e, 2 * li + 1) ? lw.d_1 : nullptr;
         fold.centre = site_centre(e, 2 * li + 2);   // ... and the MLP-down GEMM's copy is LN1's operand of the next layer
         if (tap != TAP_U && fused_mlp_for_rows(e, M)) {
@@ -1073,6 +1091,7 @@ static Ws ws_slice(ivit_engine* e, int b0) {
     w.att8 = e->att8 ? e->att8 + rt * e->ld8d : nullptr;
     w.u8 = e->u8 ? e->u8 + rt * e->ld8m : nullptr;
     w.ln_part = e->ln_part + rt * GEMM_LN_SLOTS;
+    w.ln_stats = e->ln_stats + rt;
     return w;
 }
 

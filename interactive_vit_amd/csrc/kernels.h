@@ -186,6 +186,7 @@ hipError_t launch_fold_ln_weights(const bf16_t* w, int ld, int rows, int cols, c
 hipError_t launch_row_stats(const float* x, int ldx, int rows, int dim, bf16_t* xb, int ldxb, float2* part, hipStream_t s, int f16 = 0, int row_step = 1, const float* centre = nullptr);   // part: [rows][GEMM_LN_SLOTS] (sum, M2) pairs, as EPI_BIAS_RESID_STATS writes them
 // atomicMax(*out, max over rows of |mean| / sqrt(var + eps)) of a [rows, dim] f32 matrix; the caller zeroes *out
 hipError_t launch_row_mean_ratio(const float* x, int ldx, int rows, int dim, float eps, const float* centre, float* out, hipStream_t s);   // out[0]: plain copy, out[1]: centred copy
+hipError_t launch_ln_finalize(const float2* part, int rows, int dim, float eps, float2* stats, hipStream_t s);   // pairs -> finished (mean, rstd) per row
 hipError_t launch_col_means(const float* x, int ldx, int rows, int dim, float* out, hipStream_t s);
 hipError_t launch_centre_dot(const bf16_t* w, int ld, int rows, int cols, int split, const float* centre, float* d, hipStream_t s, int f16);
 // strided row gather: out[i,:] = in[i*row_stride, :dim]  (the `cls` node)

@@ -563,6 +563,20 @@ hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
     return f32 ? launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb_f32, p, stream) : launch_sb<Tile128>(ivit_gemm_fp8_128x128x128_sb, p, stream);
 }
 
+// (mean, rstd) of every row from its statistics pairs, once, for the consumers that would otherwise fold the same pairs at the start of every column tile
+// (GemmParams::ln_stats): with 12 - 20 column tiles of 256 per row block (ViT-L / ViT-H) that redundant fold was 35 - 50 us per GEMM.  The same function, so the
+// same bits.
+__global__ __launch_bounds__(256) void ivit_ln_finalize(const float2* __restrict__ part, int rows, int dim, float eps, float2* __restrict__ stats) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m < rows) stats[m] = ln_row_stats_from_pairs(part, m, dim, eps);
+}
+
+hipError_t launch_ln_finalize(const float2* part, int rows, int dim, float eps, float2* stats, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ivit_ln_finalize, dim3(ceil_div(rows, 256)), dim3(256), 0, s, part, rows, dim, eps, stats);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
     return launch_gemm_variant(p, gemm_pick_variant(p.M, p.N, p.K), stream);
 }

@@ -207,7 +207,7 @@ def per_gemm_layer_check(eng, cfg, sd, layer, tok_gpu, sel, scales4=None):
     assert e <= F32_TOL
 
 
-def run_config(model, batch, precision, expect_gemm, expect_fold, layers_to_check, layer_tol, sd=None, calibrate_fold=False):
+def run_config(model, batch, precision, expect_gemm, expect_fold, layers_to_check, layer_tol, sd=None, calibrate_fold=False, big_fold=False):
     """sd: a weight set other than the seeded N(0, 0.02^2) one; calibrate_fold: run ivit_ln_fold_calibrate on four of the images first, as the plugin
     backend does for whatever state dict it is handed (the 16-bit copies are then centred and the oracle mirrors the vectors: vo.LN_CENTRE)."""
     from interactive_vit_amd.engine import Engine
@@ -243,7 +243,9 @@ def run_config(model, batch, precision, expect_gemm, expect_fold, layers_to_chec
             att = "ivit_attention_q32" if vo.engine_attention_form(cfg.tokens, cfg.head_dim) == "q32" else "ivit_attention_bf16"
             assert f"attention:{att}" in kern, (att, sorted(kern))
             n_ln = sum(v["launches"] for k, v in kern.items() if k.startswith("layernorm"))
-            assert n_ln == (1 if expect_fold else 2), kern       # fold: only the row statistics of the layer's input
+            # fold: only the row statistics of the layer's input - plus, where the grids are many 256-wide column tiles (ViT-L / ViT-H batches), the kernel that
+            # folds the statistics pairs once per row in front of each of the two folded GEMMs (launch_ln_finalize)
+            assert n_ln == ((3 if big_fold else 1) if expect_fold else 2), kern
             assert torch.equal(out, eng.run_node(f"encoder.layers.{layer}", tok_gpu)), "not deterministic"
             perm = torch.randperm(batch, generator=torch.Generator().manual_seed(layer))
             outp = eng.run_node(f"encoder.layers.{layer}", tok_gpu[perm.cuda()].contiguous())
@@ -290,9 +292,9 @@ def test_config2_vit_b16_batch64_as_dispatched():
 def test_config3_vit_l16_384_batch128_as_dispatched():
     """BASELINE configs[2]: 73 856 token rows - every encoder GEMM on the staggered 256x256 tile with the classic
     epilogues, LayerNorm as a kernel, attention over 577 keys by the 32-query tiled kernel (ivit_attention_q32; asserted in run_config)."""
-    k = "ivit_gemm_bf16_256x256x64_stag"     # "_f32": the f32-output epilogues (residual add) are their own instantiations since round 4
-    run_config("vit_l_16_384", 128, "bf16", {"qkv": k, "proj": k + "_f32", "mlp1": k, "mlp2": k + "_f32"},
-               expect_fold=False, layers_to_check=(0, 23), layer_tol=1e-3)
+    k = "ivit_gemm_bf16_256x256x64_stag"     # round 5: LayerNorm folded here too (_lf / _rs), the statistics pairs folded once per row by ivit_ln_finalize
+    run_config("vit_l_16_384", 128, "bf16", {"qkv": k + "_lf", "proj": k + "_rs", "mlp1": (k + "_lf", "ivit_gemm_bf16_64x128x64_deep_lf"), "mlp2": k + "_f32"},   # (a single layer node: no statistics for a next layer)
+               expect_fold=True, big_fold=True, layers_to_check=(0, 23), layer_tol=1e-3)
 
 
 def test_config4_vit_b16_batch256_as_dispatched():
@@ -309,8 +311,8 @@ def test_config5_vit_h14_batch256_bf16_as_dispatched():
     k = "ivit_gemm_bf16_256x256x64_stag"
     # 65 792 token rows = 257 row tiles: the grids of the residual GEMMs and of MLP up end on 5 ... 20 tiles, which go out as a launch of their own (round 5: tail split)
     tail = "ivit_gemm_bf16_64x128x64_deep"
-    run_config("vit_h_14", 256, "bf16", {"qkv": k, "proj": (k + "_f32", tail + "_f32"), "mlp1": (k, tail), "mlp2": (k + "_f32", tail + "_f32")},
-               expect_fold=False, layers_to_check=(0, 31), layer_tol=1.3e-3)   # measured 1.02e-3 (five chained roundings, K = 1280 / 5120); every step alone is gated above
+    run_config("vit_h_14", 256, "bf16", {"qkv": k + "_lf", "proj": (k + "_rs", tail + "_rs"), "mlp1": (k + "_lf", tail + "_lf"), "mlp2": (k + "_f32", tail + "_f32")},
+               expect_fold=True, big_fold=True, layers_to_check=(0, 31), layer_tol=1.3e-3)   # measured 1.02e-3 (five chained roundings, K = 1280 / 5120); every step alone is gated above
 
 
 def test_config5_vit_h14_batch256_fp8_as_dispatched():
