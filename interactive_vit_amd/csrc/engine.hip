@@ -898,15 +898,36 @@ static int run_layer(ivit_engine* e, const Ws& w, hipStream_t st, int li, int B,
         if (tap != TAP_U && fused_mlp_for_rows(e, M)) {
             // MLP up + GELU + MLP down + residual (+ the next layer's statistics pairs and 16-bit copy) in one launch: bit-identical to the two GEMM launches
             // below (tests), the hidden tensor never leaves the CU.  (The TAP_U inspector takes the two-launch path: it wants the hidden tensor itself.)
+            // Tail rows.  The grid runs in rounds of one workgroup per CU; a last round of a few workgroups costs what a lone workgroup costs - its 9.4 MB weight stream
+            // through ONE CU's load path, ~90 us - on an otherwise idle chip (ViT-B/16 B = 256: 788 blocks = 3 rounds + 20).  Those rows take the two GEMM launches
+            // instead (small tiles, ~40 us together); the kernel is bit-identical to them, so which rows go where changes no bit.  IVIT_MLP_TAIL=0: off.
+            int Mf = M;
+            {
+                static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
+                static const bool on = [] { const char* v = getenv("IVIT_MLP_TAIL"); return !(v && atoi(v) == 0); }();
+                const int blocks = (M + 63) / 64, rem = blocks % cus;
+                if (on && blocks > cus && rem > 0 && rem * 4 <= cus) Mf = (blocks - rem) * 64;
+            }
             MlpFusedParams mp{};
             mp.X = w.h; mp.ldx = D; mp.ln_part_in = w.ln_part; mp.ln_eps = e->cfg.ln_eps; mp.Wp = lw.wp_mlp; mp.c1 = lw.c_1; mp.s1 = lw.s_1; mp.b2 = lw.b2;
             mp.resid = w.x; mp.ldr = D; mp.out = xo; mp.ldo = D; mp.xb = w.h; mp.ldxb = D; mp.ln_part_out = w.ln_part;
             mp.d1 = fold.d; mp.centre_out = fold.centre;
-            mp.M = M; mp.D = D; mp.Mlp = Mlp; mp.f16 = e->f16; mp.split = mlp_split_mode(e); mp.stats_out = stats_out ? 1 : 0;
-            const double flops = 4.0 * M * (double)D * Mlp;
-            const double bytes = 2.0 * M * D + (double)mlp_fused_packed_bytes(D, Mlp, mlp_split_mode(e)) + 8.0 * M * D + (stats_out ? 2.0 * M * D : 0.0);
-            ProfScope ps(e, PC_GEMM, st, flops, bytes, "mlp", mlp_fused_kernel_name(mp));
-            HIP_TRY(launch_mlp_fused(mp, st));
+            mp.M = Mf; mp.D = D; mp.Mlp = Mlp; mp.f16 = e->f16; mp.split = mlp_split_mode(e); mp.stats_out = stats_out ? 1 : 0;
+            const double flops = 4.0 * Mf * (double)D * Mlp;
+            const double bytes = 2.0 * Mf * D + (double)mlp_fused_packed_bytes(D, Mlp, mlp_split_mode(e)) + 8.0 * Mf * D + (stats_out ? 2.0 * Mf * D : 0.0);
+            {
+                ProfScope ps(e, PC_GEMM, st, flops, bytes, "mlp", mlp_fused_kernel_name(mp));
+                HIP_TRY(launch_mlp_fused(mp, st));
+            }
+            if (Mf < M) {
+                const int Mt = M - Mf;
+                const size_t off = (size_t)Mf;
+                LnFold ft = fold;   // the same vectors; row pointers advanced to the tail
+                ft.part = w.ln_part + off * GEMM_LN_SLOTS; ft.xb = w.h + off * D; ft.stats = nullptr;
+                if (run_gemm(e, st, w.h + off * D, D, lw.wf_1, Mt, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &ft, "mlp1")) return 1;
+                if (stats_out) return run_gemm(e, st, w.u, Mlp, lw.w2, Mt, lw.b2, EPI_BIAS_RESID_STATS, xo + off * D, D, w.x + off * D, D, nullptr, 0, 0, 0, 0, &ft, "mlp2");
+                return run_gemm(e, st, w.u, Mlp, lw.w2, Mt, lw.b2, EPI_BIAS_RESID_F32, xo + off * D, D, w.x + off * D, D, nullptr, 0, 0, 0, 0, nullptr, "mlp2");
+            }
             return 0;
         }
         if (run_gemm(e, st, w.h, D, lw.wf_1, M, lw.c_1, EPI_LNFOLD_GELU_BF16, w.u, Mlp, nullptr, 0, nullptr, 0, 0, 0, 0, &fold, "mlp1")) return 1;

@@ -303,7 +303,8 @@ def test_config4_vit_b16_batch256_as_dispatched():
     256 x 256 tiles at N = 768: below the 3 rounds at which the residual GEMMs move to that tile), QKV and MLP up take the 256 x 256
     tile with the fold epilogue (9.9 / 13 rounds), out-projection (and MLP down, where the MLP pair is not fused) the three-per-CU 160 x 128 tile."""
     k256, k160 = "ivit_gemm_bf16_256x256x64_stag_lf", "ivit_gemm_bf16_160x128x64_sb"
-    run_config("vit_b_16", 256, "bf16", {"qkv": k256, "proj": k160 + "_rs", "mlp": "ivit_mlp_fused_bf16_d768"},   # round 5: the MLP pair in one launch (788 workgroups = 3.08 rounds of 256)
+    run_config("vit_b_16", 256, "bf16", {"qkv": k256, "proj": k160 + "_rs", "mlp": "ivit_mlp_fused_bf16_d768",   # round 5: the MLP pair in one launch - 768 of the 788 row blocks = 3 whole rounds;
+                                         "mlp1": "ivit_gemm_bf16_128x128x64_sb_lf", "mlp2": "ivit_gemm_bf16_64x128x64_deep_f32"},   # the last 20 blocks (a lone round) as the GEMM pair on small tiles: the same bits
                expect_fold=True, layers_to_check=(0, 11), layer_tol=1e-3)
 
 
