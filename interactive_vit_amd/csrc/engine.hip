@@ -820,13 +820,17 @@ static bool fold_for_rows(const ivit_engine* e, int M) {
 // ... with the statistics finalised by a kernel where the QKV / MLP-up grids are many column tiles of 256 wide
 static bool fold_finalize_for_rows(const ivit_engine* e, int M) { return gemm_prefers_256(M, e->D, e->D); }
 
-// The fused MLP kernel runs one workgroup of 64 rows per CU: it takes the calls whose grids fill at least 70 % of the CU slots of their last round
-// (ViT-B/16: B = 64 -> 197 workgroups, B = 256 -> 788 = 3.08 rounds); below that - the interactive path - the GEMM pair on its small tiles is faster.
+// The fused MLP kernel runs one workgroup of 64 rows per CU.  It takes the calls whose grid is whole rounds of the chip's CUs plus a last round that is either
+// at least 70 % full (ViT-B/16: B = 64 -> 197 workgroups) or at most a quarter full - those rows then go to the GEMM pair (run_layer: tail rows; B = 256 -> 788 =
+// 3 rounds + 20; B = 96 -> 256 + 40: 20.1 -> 20.8 k img/s).  In between (B = 112: 256 + 89) and below 70 % of one round - the interactive path - the GEMM pair on
+// its own tiles is faster (profiles/r05_fused_mlp.txt).
 static bool fused_mlp_for_rows(const ivit_engine* e, int M) {
     if (!e->fused_mlp) return false;
     static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
-    const int wgs = (M + 63) / 64, rounds = (wgs + cus - 1) / cus;
-    return 10 * wgs >= 7 * rounds * cus;
+    static const bool tail = [] { const char* v = getenv("IVIT_MLP_TAIL"); return !(v && atoi(v) == 0); }();
+    const int wgs = (M + 63) / 64, rem = wgs % cus;
+    if (10 * wgs < 7 * cus) return false;
+    return rem == 0 || 10 * rem >= 7 * cus || (tail && wgs > cus && rem * 4 <= cus);
 }
 
 // bf16 layer; amax4 != nullptr (calibration): record max|.| of the four GEMM-input tensors.
