@@ -1,4 +1,4 @@
-# config 3 (ViT-L/16-384 B = 128): LayerNorm kernels (default) vs the fold forced (IVIT_FOLD_LN=2), with the out-projection on three 160 x 128 per CU (IVIT_SQUARE_160=1)
+# config 3 / ViT-H: the LayerNorm fold with one statistics kernel per LayerNorm (the default since round 5) vs rounds 3-4's rule (IVIT_FOLD_LN=3: LayerNorm kernels at these batches)
 run() {
   n=$1; shift
   env "$@" > gpurun_out/abl_$n.json 2> gpurun_out/abl_$n.err || { tail -5 gpurun_out/abl_$n.err; return 1; }
@@ -13,8 +13,8 @@ PY
 }
 B="timeout -k 10 400 python bench.py --no-cpu-baseline --no-tolerance-mode --no-layernorm-leg --steps 10 --warmup 3"
 for i in 1 2; do
-run c3_base_$i $B --config 3 || exit 1
-run c3_fold_$i IVIT_FOLD_LN=2 $B --config 3 || exit 1
+run c3_base_$i IVIT_FOLD_LN=3 $B --config 3 || exit 1
+run c3_fold_$i $B --config 3 || exit 1
 done
-run h14_base $B --model vit_h_14 --batch-per-gpu 256 --precision bf16 || exit 1
-run h14_fold IVIT_FOLD_LN=2 $B --model vit_h_14 --batch-per-gpu 256 --precision bf16 || exit 1
+run h14_base IVIT_FOLD_LN=3 $B --model vit_h_14 --batch-per-gpu 256 --precision bf16 || exit 1
+run h14_fold $B --model vit_h_14 --batch-per-gpu 256 --precision bf16 || exit 1
