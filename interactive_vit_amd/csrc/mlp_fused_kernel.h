@@ -14,8 +14,9 @@
 // launch_gemm(EPI_LNFOLD_GELU_BF16) + launch_gemm(EPI_BIAS_RESID_STATS) (tools/mlp_fused_bench, tests/test_gpu_parity.py).
 //
 // What bounds it: weights.  Every workgroup streams all of W1' and W2 (9.4 MB at ViT-B/16): 393 KB per chunk against 6.1 k cycles of MFMA - 1.86 GB per
-// launch out of the XCDs' L2s at ViT-B/16 B = 64 (13.6 TB/s aggregate; a CU's own return path, 42-52 B/clk, profiles/r03b_operand_path_probe.txt, is not the
-// limit: handing a sixth of every block's chunks to the CUs a 197-block grid leaves idle made nothing faster, profiles/r05_fused_mlp.txt).  The first structure (weights through a
+// launch out of the XCDs' L2s at ViT-B/16 B = 64, ~120 us per workgroup + a 15 us epilogue burst.  (Measured and not explained by either simple model: half
+// the row blocks alone take 125 us, and handing a sixth of every block's chunks to the CUs a 197-block grid leaves idle made nothing faster:
+// profiles/r05_fused_mlp.txt.)  The first structure (weights through a
 // ring of LDS buffers, one barrier per 16-KiB slot: profiles/r05_fused_mlp_v1.txt) lost to the two launches - the LDS that X leaves holds too
 // little DMA in flight, and in barrier lockstep MFMA, LDS reads and DMA do not overlap.  This one shares NO weight fragment between waves:
 //   * 1 x 8 wave layout: wave w owns ALL 64 rows and, in phase 1, hidden columns 16 w .. of the chunk (4 x 1 fragments), in phase 2 the output
