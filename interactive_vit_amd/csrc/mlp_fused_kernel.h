@@ -28,7 +28,7 @@
 //   * LDS holds X (ND x 8 KiB, read 8 x redundantly: 4 fragment reads per K-step) and two U buffers; ONE s_barrier per chunk (U written ->
 //     U read; the second buffer makes the write-after-read side free), so the waves of a CU drift apart and fill each other's stalls.
 // The residual / statistics epilogue: a wave's whole slot is the (FM = 4, FN = 4) epilogue of the GEMM kernels; the two halves of a shared slot
-// chain their row sums through LDS in the GEMM epilogue's own order (three barriers, once per kernel), so the pairs come out bit-identical too.
+// hand the even wave.s values to the odd one through LDS, which sums in the GEMM epilogue.s own order (one barrier), so the pairs come out bit-identical too.
 #pragma once
 #include "gemm_kernel.h"
 #include <utility>
@@ -297,6 +297,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
     IVIT_MLPF_STAMP(2);
 #pragma unroll
     for (int b = 0; b < R; ++b) asm volatile("" ::"v"(wq[b]));   // the look-ahead past the last chunk is waited for, not dropped mid-flight
+    IVIT_MLPF_STAMP(4);
 
     // ---------------- residual epilogue of the MLP-down GEMM
     // (the row base and the lane's fragment coordinates re-enter through an opaque statement: hipcc otherwise computes the epilogue's row addresses ABOVE the
@@ -326,12 +327,10 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
     // the wave's own slot: exactly the (FM = 4, FN = 4) epilogue of the GEMM kernels
     if (p.stats_out) gemm_epilogue_family<T, 1, OP, IVIT_MLPF_EPI_G>(gp, accF, m0e, 64 * wave, fre, fqe);
     else gemm_epilogue_family<T, 3, OP, IVIT_MLPF_EPI_G>(gp, accF, m0e, 64 * wave, fre, fqe);
+    IVIT_MLPF_STAMP(5);
     if constexpr (NH > 0) {
-        // the shared slot 8 + w / 2: the even wave holds its fragments j = 0, 1, the odd wave j = 2, 3.  Same element arithmetic; the slot's row sum and
-        // M2 are the GEMM epilogue's sequential lane sums (j, then r), so the two waves CHAIN them through LDS: even -> odd (sum), odd -> even (slot
-        // mean), even -> odd (M2), a barrier each.  The scratch is the U buffer the last chunk did not use.
+        // the shared slot 8 + w / 2: the even wave holds its fragments j = 0, 1, the odd wave j = 2, 3.  Same element arithmetic; the slot's statistics below.
         static_assert(NH == 0 || NH == 2, "half of a four-fragment slot");
-        float* xch = reinterpret_cast<float*>(ubuf + (nchunks & 1) * G::U_BYTES) + (wave >> 1) * 1024;   // three arrays of [4 i][64 lanes] per wave pair
 #pragma unroll
         for (int j = 0; j < 2; ++j) bias_h[j] = *reinterpret_cast<const float4*>(p.b2 + n0 + 16 * j + 4 * fqe);
         // rn16(x - centre) where the next LayerNorm's operand rows are centred (kernels.h: ln_centre); requested ahead of the rows' stores (loads and stores
@@ -341,11 +340,9 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
             ca = *reinterpret_cast<const float4*>(p.centre_out + n0 + 4 * fqe);
             cb = *reinterpret_cast<const float4*>(p.centre_out + n0 + 16 + 4 * fqe);
         }
-        float sum[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int mr = row_ok[i] ? m0e + 16 * i + fre : p.M - 1;
-            sum[i] = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float v[4] = {xh[i][j].x + (accH[i][j][0] + bias_h[j].x), xh[i][j].y + (accH[i][j][1] + bias_h[j].y),
@@ -361,63 +358,47 @@ __device__ __forceinline__ void mlp_fused_body(const MlpFusedParams& p, char* sm
                 if (row_ok[i]) *reinterpret_cast<u32x4*>(p.xb + (size_t)mr * p.ldxb + n0 + (fqe & 1) * 16 + (fqe & ~1) * 4) = pk;
             }
         }
-        if (p.stats_out) {   // (uniform branch: every wave takes the same barriers)
-            // 1. sequential lane sum: even wave starts from 0 over its 8 values, odd wave continues from the even wave's partial
+        IVIT_MLPF_STAMP(6);
+        if (p.stats_out) {   // (uniform branch: every wave takes the same barrier)
+            // The slot's row sum and M2 are the GEMM epilogue's sequential lane sums over the 16 values a lane would hold (j = 0..3, then r), i.e. the even wave's
+            // 8 values then the odd wave's.  The even wave hands its 8 values per row to its partner through LDS - quads at [(i, j)][lane]: the partner's same lane
+            // holds the same (row, column quad) - and the ODD wave evaluates both statistics alone, in that order: one barrier (round 5a chained sum -> mean -> M2
+            // between the two waves through three: 4.9 us of the 15.6 us epilogue).  The scratch is X's K-tiles 1 .. 4: dead since the last chunk's phase 1 (a wave still
+            // in that chunk's phase 2 reads only U and, for the look-ahead, X's K-tile 0).
+            float4* xq = reinterpret_cast<float4*>(smem + 8192 + (wave >> 1) * 8192);
             if (!odd) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sum[i] += accH[i][j][r];
-                    xch[i * 64 + lane] = sum[i];
-                }
+                    for (int j = 0; j < 2; ++j) xq[(i * 2 + j) * 64 + lane] = make_float4(accH[i][j][0], accH[i][j][1], accH[i][j][2], accH[i][j][3]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            float lmean[4] = {0.f, 0.f, 0.f, 0.f};
             if (odd) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float s_ = xch[i * 64 + lane];
+                    const float4 e0 = xq[(i * 2 + 0) * 64 + lane], e1 = xq[(i * 2 + 1) * 64 + lane];
+                    const float ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                    float s_ = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s_ += ev[k];
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) s_ += accH[i][j][r];
                     s_ += __shfl_xor(s_, 16, 64);
                     s_ += __shfl_xor(s_, 32, 64);
-                    sum[i] = s_;
-                    lmean[i] = s_ / 64.0f;
-                    xch[256 + i * 64 + lane] = lmean[i];
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (!odd) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float lm = xch[256 + i * 64 + lane];
+                    const float lm = s_ / 64.0f;
                     float q2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const float d = ev[k] - lm; q2 = fmaf(d, d, q2); }
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float d = accH[i][j][r] - lm; q2 = fmaf(d, d, q2); }
-                    xch[512 + i * 64 + lane] = q2;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (odd) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float q2 = xch[512 + i * 64 + lane];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float d = accH[i][j][r] - lmean[i]; q2 = fmaf(d, d, q2); }
                     q2 += __shfl_xor(q2, 16, 64);
                     q2 += __shfl_xor(q2, 32, 64);
-                    if (fqe == 0 && row_ok[i]) p.ln_part_out[(size_t)(m0e + 16 * i + fre) * GEMM_LN_SLOTS + hslot] = make_float2(sum[i], q2);
+                    if (fqe == 0 && row_ok[i]) p.ln_part_out[(size_t)(m0e + 16 * i + fre) * GEMM_LN_SLOTS + hslot] = make_float2(s_, q2);
                 }
             }
         }

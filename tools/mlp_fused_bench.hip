@@ -167,6 +167,9 @@ int main(int argc, char** argv) {
                 // s_memrealtime ticks at 100 MHz
                 printf("      per workgroup (mean over %d, us): start skew %.2f | prologue %.2f | chunk loop %.2f | epilogue %.2f | last workgroup ends at %.2f\n", nwg,
                        s[0] / nwg / 100, s[1] / nwg / 100, s[2] / nwg / 100, s[3] / nwg / 100, last / 100);
+                double e4 = 0, e5 = 0, e6 = 0, e7 = 0;   // wave 0's epilogue: ring drained | own slot done | shared-slot values stored | statistics chain + end
+                for (int b = 0; b < nwg; ++b) { e4 += (double)(h[b * 8 + 4] - h[b * 8 + 2]); e5 += (double)(h[b * 8 + 5] - h[b * 8 + 4]); e6 += (double)(h[b * 8 + 6] - h[b * 8 + 5]); e7 += (double)(h[b * 8 + 3] - h[b * 8 + 6]); }
+                printf("         epilogue of wave 0: look-ahead drained %.2f | own slot %.2f | shared-slot values %.2f | statistics chain %.2f\n", e4 / nwg / 100, e5 / nwg / 100, e6 / nwg / 100, e7 / nwg / 100);
             }
         };
         study(mlpf_study_bf16<0>, "study build, as the product", true);
