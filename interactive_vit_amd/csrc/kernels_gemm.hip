@@ -566,14 +566,14 @@ hipError_t launch_gemm_fp8(const GemmParams& p, hipStream_t stream) {
 // (mean, rstd) of every row from its statistics pairs, once, for the consumers that would otherwise fold the same pairs at the start of every column tile
 // (GemmParams::ln_stats): with 12 - 20 column tiles of 256 per row block (ViT-L / ViT-H) that redundant fold was 35 - 50 us per GEMM.  The same function, so the
 // same bits.
-__global__ __launch_bounds__(256) void ivit_ln_finalize(const float2* __restrict__ part, int rows, int dim, float eps, float2* __restrict__ stats) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void ivit_ln_finalize(const float2* __restrict__ part, int rows, int dim, float eps, float2* __restrict__ stats) {
+    const int m = blockIdx.x * 64 + threadIdx.x;   // (one wave per workgroup: 73 856 rows = 1 154 waves, four or five per CU, instead of two rounds of four-wave workgroups)
     if (m < rows) stats[m] = ln_row_stats_from_pairs(part, m, dim, eps);
 }
 
 hipError_t launch_ln_finalize(const float2* part, int rows, int dim, float eps, float2* stats, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ivit_ln_finalize, dim3(ceil_div(rows, 256)), dim3(256), 0, s, part, rows, dim, eps, stats);
+    hipLaunchKernelGGL(ivit_ln_finalize, dim3(ceil_div(rows, 64)), dim3(64), 0, s, part, rows, dim, eps, stats);
     return hipGetLastError();
 }
 
