@@ -191,6 +191,23 @@ def test_centred_fold_algebra_is_the_plain_layer():
         vo.ROUND_ONLY, vo.LN_FOLD, vo.LN_CENTRE = saved
 
 
+def test_realistic_statistics_weights_have_the_statistics_they_claim():
+    """weights.realistic_statistics_weights (what the LayerNorm-fold calibration is tested and benchmarked on: tests/test_gpu_configs.py, bench.py --weights
+    realistic): deterministic, the same tensor names and shapes as the seeded set, token rows whose |mean| / std reaches 2 and more (the plain 16-bit copy of such rows is
+    what rounds 3-4's guard refused), and offsets that are constant across rows - so the per-channel means the calibration takes remove them."""
+    from interactive_vit_amd.weights import realistic_statistics_weights
+    cfg = small_config(name="vit_realstats", image=64, patch=16, dim=768, heads=12, layers=1, mlp=3072, classes=8)   # ViT-B width: the hot channels are 4 of 768
+    a, b = realistic_statistics_weights(cfg, seed=21), realistic_statistics_weights(cfg, seed=21)
+    ref = init_weights(cfg, seed=21, mode="rich")
+    assert sorted(a) == sorted(ref) and all(a[k].shape == ref[k].shape and torch.equal(a[k], b[k]) for k in a)
+    x = synthetic_images(2, cfg, seed=5)
+    tok = vo.forward(x, a, cfg, keep=True)["tokens"].reshape(-1, cfg.dim)
+    assert float((tok.mean(-1).abs() / tok.std(-1)).max()) >= 2.0            # the guard statistic is a maximum over rows
+    centred = tok - tok.mean(0, keepdim=True)
+    ratio = (centred.pow(2).mean(-1) / tok.var(-1, unbiased=False)).sqrt()       # rms of the centred row over the row's own spread: the fold's noise factor
+    assert float(ratio.max()) <= 1.12, float(ratio.max())                      # <= 12 % more noise than LayerNorm kernels: the guard's threshold 0.5 as a factor
+
+
 def test_seeded_weights_and_image_are_pinned():
     cfg = VARIANTS[VGOLD["config"]]
     sd = init_weights(cfg, seed=VGOLD["weights"]["seed"], mode=VGOLD["weights"]["mode"])
