@@ -598,7 +598,7 @@ int gemm_tail_rows(const GemmParams& p, bool fp8) {
     if (wide < 2 && gemm_family(p.epi) != 3 && gemm_family(p.epi) != 1 && p.K < 2048 && p.N < 4 * p.K) return 0;   // (N >= 4 K: MLP up - ViT-L/16-384 B = 128 662 -> 648 us, ViT-H 846 -> 839)
     const bool t256 = fp8 ? fp8_tile(p) == GEMM_TILE_256S : gemm_pick_variant(p.M, p.N, p.K) == GEMM_TILE_256S;
     if (!t256) return 0;
-    const int cus = device_cu_count();
+    static const int cus = device_cu_count();   // (one device per process: one process per GPU)
     const int tm = ceil_div(p.M, 256), tn = ceil_div(p.N, 256), tiles = tm * tn, rem = tiles % cus;
     if (tiles < 3 * cus || rem == 0 || (wide >= 2 ? rem * 10 > cus * 6 : rem * 8 > cus)) return 0;
     const int r = ceil_div(rem, tn);
